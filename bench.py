@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic QPs that is already resident
+in HBM:  z = QPFunction(verbose=-1)(Q, p, G, h, A, b); z.backward(ones)   (forward + backward,
+the measurement defined in SURVEY.md section 8d / prof-linear.py:110-118, device-synchronised).
+Workload = BASELINE.json configs[1] extended with the backward pass as its `metric` asks:
+batch=512, nz=100, nineq=100, neq=0 per GPU, float64 (the dtype the 1e-4 parity gate holds in).
+With N GPUs every rank solves its own 512-QP shard (the batch dimension shards with no
+data-path collective) => weak scaling; value = N*512*K / max-over-ranks time.
+
+The JSON line also carries
+  roofline ...... the dominant kernel (k_ipm, the PDIPM loop): algorithmic bytes per launch /
+                  average launch duration measured live with HIP events on the launch stream
+  cpu_baseline .. the oracle (C restatement of the reference's CPU path) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import problems  # noqa: E402
+from qpth_amd.qp import QPFunction  # noqa: E402
+from qpth_amd.kkt import KKTFactors, set_stall_policy  # noqa: E402
+from qpth_amd import _lib  # noqa: E402
+
+HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def algorithmic_bytes_per_qp(n, m, q, w):
+    """compulsory HBM traffic per QP (forward read+write, backward read+write)."""
+    fwd_r = w * (n * n + m * n + q * n + n + m + q)
+    fwd_w = w * (n + 2 * m + q)
+    bwd_r = w * (n * n + m * n + q * n + 2 * n + 2 * m + q)
+    bwd_w = w * (n * n + n + m * n + m + q * n + q)
+    return fwd_r, fwd_w, bwd_r, bwd_w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--nz", type=int, default=100)
+    ap.add_argument("--nineq", type=int, default=100)
+    ap.add_argument("--neq", type=int, default=0)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to time.")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    B, n, m, q = args.batch, args.nz, args.nineq, args.neq
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    w = 8 if args.dtype == "f64" else 4
+    # every rank owns its own shard: different seed per rank, same generator (prof-linear.py:64-75)
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed=rank, dtype=np_dt)
+    tQ, tp, tG, th, tA, tb = [torch.tensor(x, device=dev) for x in (Q, p, G, h, A, b)]
+    tp.requires_grad_(True)                      # prof-linear.py:99
+    ones = torch.ones(B, n, dtype=tQ.dtype, device=dev)
+    qpf = QPFunction(verbose=-1)
+
+    def step():
+        z = qpf(tQ, tp, tG, th, tA, tb)
+        z.backward(ones)
+        tp.grad = None
+        return z
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        z = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        # ---- per-kernel timing with HIP events on the launch stream (torch's current stream) ----
+        fac = KKTFactors.build(tQ, tG, tA, B)
+        res = fac.ipm(tp.detach(), th, tb)
+        torch.cuda.synchronize()
+        iters_mean = float(res.iters.float().mean().item())
+        nrep = max(5, min(args.steps, 30))
+
+        def time_launches(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(nrep):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / nrep * 1e-3
+
+        t_pre = time_launches(lambda: KKTFactors.build(tQ, tG, tA, B))
+        t_ipm = time_launches(lambda: fac.ipm(tp.detach(), th, tb))
+        t_bwd = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones))
+        set_stall_policy(_lib.STALL_OFF)
+        t_ipm_fixed = time_launches(lambda: fac.ipm(tp.detach(), th, tb))
+        set_stall_policy(None)
+
+        fwd_r, fwd_w, bwd_r, bwd_w = algorithmic_bytes_per_qp(n, m, q, w)
+        ipm_bytes = (fwd_r + fwd_w) * B          # the forward's compulsory traffic, DESIGN.md section 6
+        achieved = ipm_bytes / t_ipm
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "ipm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                rec = json.load(open(tf))
+                if rec.get("config") == [B, n, m, q, args.dtype]:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "k_ipm", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": ipm_bytes, "launch_ms": t_ipm * 1e3}
+
+        cpu_baseline = None
+        if not args.no_cpu_baseline:
+            from oracle import qp_oracle as orc
+            cores = os.cpu_count() or 1
+            best = None
+            for rep in range(3):
+                c0 = time.perf_counter()
+                o = orc.OracleQP(Q, p, G, h, A, b, nthreads=cores)
+                x, y, lam, s, info = o.forward()                      # reference (batch-global) semantics
+                o.backward(x, lam, s, y, np.ones((B, n), np_dt))
+                c1 = time.perf_counter() - c0
+                best = c1 if best is None else min(best, c1)
+            cpu_baseline = {"value": B / best, "unit": "QPs/s", "cores": cores, "kind": "port",
+                            "sample": "the full workload once (B=%d fwd+bwd, best of 3, %s, %d IPM iterations, "
+                                      "OpenMP over QPs)" % (B, args.dtype, int(info["trips"]))}
+
+        out = {
+            "metric": "QPs/sec (fwd+bwd) at batch=512 nz=100 nineq=100; 1/2/4/8 MI355X",
+            "value": value, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "C2 fwd+bwd: batch=%d nz=%d nineq=%d neq=%d per GPU, dense random QP "
+                                   "(prof-linear.py generator), QPFunction(verbose=-1) defaults" % (B, n, m, q),
+                       "global_batch": world * B, "parallelism": "batch-sharded x%d" % world,
+                       "ipm_iterations_mean": iters_mean},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernel_ms": {"pre_factor": t_pre * 1e3, "ipm": t_ipm * 1e3, "backward": t_bwd * 1e3,
+                          "ipm_all_%d_iterations" % 20: t_ipm_fixed * 1e3},
+            "job_hbm_roofline_frac": value / world * (fwd_r + fwd_w + bwd_r + bwd_w) / HBM_PEAK,
+        }
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

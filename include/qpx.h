@@ -1,0 +1,126 @@
+/*
+ * qpx.h -- C ABI of libqpx_hip.so: the MI355X (gfx950) implementation of the one hot path of
+ * locuslab/qpth, the dense batched primal-dual interior-point QP solver and its backward pass.
+ *
+ *     z* = argmin_z 1/2 z'Qz + p'z   s.t.  Gz <= h,  Az = b        (qpth/qp.py:32-42)
+ *
+ * Every entry point replaces one solver entry point of the reference (the seam that
+ * qpth/qp.py:92-96,148-155 calls through):
+ *
+ *   qpx_pre_factor ........ qpth/solvers/pdipm/batch.py:375-429   pre_factor_kkt(Q, G, A)
+ *   qpx_ipm ............... qpth/solvers/pdipm/batch.py:47-207    forward(Q,p,G,h,A,b,Q_LU,S_LU,R,...)
+ *   qpx_forward ........... qpth/qp.py:92-96                       pre_factor_kkt + forward
+ *   qpx_factor_solve_kkt .. qpth/solvers/pdipm/batch.py:435-470 + 349-372
+ *                                                                  factor_kkt(S_LU,R,d); solve_kkt(...)
+ *   qpx_backward .......... qpth/qp.py:127-182                     QPFunctionFn.backward (per-QP grads)
+ *
+ * Conventions
+ *   - dtype: QPX_F32 or QPX_F64; every `void*` array below has that element type.
+ *   - All pointers are DEVICE pointers valid on `stream` (a hipStream_t).  The caller owns every
+ *     buffer; the library never allocates, frees or synchronises.  Calls are stream-ordered and
+ *     re-entrant (no global state).
+ *   - Arrays are dense, row-major, batch-major: Q (B,n,n), p (B,n), G (B,m,n), h (B,m),
+ *     A (B,q,n), b (B,q).  A batch stride (in elements) of 0 means "one copy shared by the whole
+ *     batch" (the reference's un-batched parameters, qpth/util.py:44-50).  q = 0: A, b unused.
+ *   - `factors`: B * qpx_factor_elems(n,m,q) elements of scratch that carries the
+ *     factorisations from qpx_pre_factor to qpx_ipm / qpx_factor_solve_kkt / qpx_backward
+ *     (what the reference stashes on ctx as Q_LU, S_LU, R; qpth/qp.py:93).  Consumers take
+ *     its batch stride `sfac` in elements: qpx_factor_elems(n,m,q), or 0 when Q, G, A are
+ *     shared by the whole batch and were factored once with B = 1 (only if qpx_fits_lds()).
+ *   - `status`: int32[B], per-QP bit mask of QPX_ST_* written on the device; the functions
+ *     themselves return 0 or a negative QPX_ERR_* launch/argument error and never throw.
+ *   - Semantics of the IPM loop are those of the reference for a batch of one per QP; see
+ *     `stall_policy` and DESIGN.md for the batch-global quirks of the reference this removes.
+ */
+#ifndef QPX_H
+#define QPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPX_ABI_VERSION 1
+
+enum { QPX_F32 = 0, QPX_F64 = 1 };
+
+enum {
+    QPX_OK = 0,
+    QPX_ERR_ARG = -1,          /* bad dtype / sizes / null pointer            */
+    QPX_ERR_UNSUPPORTED = -2,  /* max(n,m,q) beyond what this build dispatches */
+    QPX_ERR_LAUNCH = -3,       /* HIP launch error (see hipGetLastError)       */
+    QPX_ERR_NO_DEVICE = -4
+};
+
+/* per-QP status bits */
+enum {
+    QPX_ST_Q_NOT_SPD = 1,      /* -> RuntimeError('Q is not SPD.')       qp.py:85          */
+    QPX_ST_A_RANK = 2,         /* A Q^-1 A^T not factorable              batch.py:407       */
+    QPX_ST_KKT_BREAKDOWN = 4,  /* factor_kkt failed, best iterate returned  batch.py:110-113 */
+    QPX_ST_INACCURATE = 8,     /* best residual > 1 -> INACC_ERR warning   batch.py:141,205  */
+    QPX_ST_MAXITER = 16,
+    QPX_ST_NONFINITE = 32
+};
+
+/* stall_policy of qpx_ipm: how `notImprovedLim` (batch.py:127-140, batch-global in the
+ * reference) is applied per QP.  0 = never stop on stall; 1 = the reference's counter per QP
+ * (identical to the reference for a batch of one); 2 = round-off-floor rule (default for B > 1). */
+enum { QPX_STALL_OFF = 0, QPX_STALL_REFERENCE = 1, QPX_STALL_FLOOR = 2 };
+
+typedef void* qpx_stream_t; /* hipStream_t */
+
+int qpx_abi_version(void);
+const char* qpx_strerror(int code);
+
+/* elements (of dtype) of factor storage per QP */
+size_t qpx_factor_elems(int n, int m, int q);
+
+/* largest max(n,m,q) this build can solve; whether (n,m,q) runs with LDS-resident matrices */
+int qpx_max_dim(void);
+int qpx_fits_lds(int dtype, int n, int m, int q);
+
+/* pre_factor_kkt(Q, G, A) */
+int qpx_pre_factor(int dtype, int B, int n, int m, int q,
+                   const void* Q, int64_t sQ, const void* G, int64_t sG, const void* A, int64_t sA,
+                   void* factors, int32_t* status, qpx_stream_t stream);
+
+/* forward(Q,p,G,h,A,b,Q_LU,S_LU,R,...): the PDIPM loop on pre-factored QPs.  Outputs in the
+ * reference's return order x, y, z, s = zhat (B,n), nu (B,q), lam (B,m), slacks (B,m);
+ * iters int32[B]; best_resid dtype[B]; trace: NULL or dtype[maxIter][B][3] = (pri_resid,
+ * dual_resid, mu) per iteration (what verbose=1 prints, batch.py:115-117). */
+int qpx_ipm(int dtype, int B, int n, int m, int q,
+            const void* p, int64_t sp, const void* h, int64_t sh, const void* b, int64_t sb,
+            void* factors, int64_t sfac, double eps, int maxIter, int notImprovedLim, int stall_policy,
+            void* zhat, void* nu, void* lam, void* slack,
+            int32_t* iters, int32_t* status, void* best_resid, void* trace, qpx_stream_t stream);
+
+/* qpx_pre_factor followed by qpx_ipm on the same stream */
+int qpx_forward(int dtype, int B, int n, int m, int q,
+                const void* Q, int64_t sQ, const void* p, int64_t sp,
+                const void* G, int64_t sG, const void* h, int64_t sh,
+                const void* A, int64_t sA, const void* b, int64_t sb,
+                void* factors, double eps, int maxIter, int notImprovedLim, int stall_policy,
+                void* zhat, void* nu, void* lam, void* slack,
+                int32_t* iters, int32_t* status, void* best_resid, void* trace, qpx_stream_t stream);
+
+/* factor_kkt(S_LU, R, d) then solve_kkt(Q_LU, d, G, A, S_LU, rx, rs, rz, ry) -> dx, ds, dz, dy.
+ * d (B,m) > 0; rx (B,n), rs, rz (B,m), ry (B,q): NULL means zeros; dy may be NULL when q = 0. */
+int qpx_factor_solve_kkt(int dtype, int B, int n, int m, int q, void* factors, int64_t sfac,
+                         const void* d, const void* rx, const void* rs, const void* rz, const void* ry,
+                         void* dx, void* ds, void* dz, void* dy, int32_t* status, qpx_stream_t stream);
+
+/* QPFunctionFn.backward for given (zhat, lam, slacks, nu) -- from qpx_ipm or from any other
+ * solver (qp.py:142-155) -- and dl_dz (B,n).  Per-QP gradients dQ (B,n,n), dp (B,n),
+ * dG (B,m,n), dh (B,m), dA (B,q,n), db (B,q); mean-reduction over a broadcast batch
+ * (qp.py:159-177) is the caller's. */
+int qpx_backward(int dtype, int B, int n, int m, int q, void* factors, int64_t sfac,
+                 const void* zhat, const void* lam, const void* slack, const void* nu, const void* dl_dz,
+                 void* dQ, void* dp, void* dG, void* dh, void* dA, void* db,
+                 int32_t* status, qpx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPX_H */

@@ -1,0 +1,67 @@
+// qpx_layout.h -- HBM layout of the per-QP "factor blob" and shared constants.
+//
+// The blob is what the reference keeps in (Q_LU, S_LU, R) between pre_factor_kkt, the IPM loop
+// and backward (qpth/solvers/pdipm/batch.py:375-429, qpth/qp.py:93,150-155), re-expressed for
+// an un-pivoted Cholesky design (SPD Q and S; the reference's own GPU branch is un-pivoted,
+// batch.py:8-20).  One blob per QP, `fac_stride` elements apart, all sub-arrays 16-byte aligned:
+//
+//   L      n(n+1)/2   Cholesky factor of Q, packed lower, row-major        (replaces Q_LU)
+//   dinvL  n          1 / L_kk
+//   Zp     n x m      P L^-1 G^T, P = projector onto null(A L^-T) (= L^-1 G^T when neq = 0)
+//   R      m(m+1)/2   Zp^T Zp = G Q^-1 G^T - G Q^-1 A^T (A Q^-1 A^T)^-1 A Q^-1 G^T, packed lower
+//                     (the reference's R, batch.py:396-399,424)
+//   Yh     n x q      L^-1 A^T L11^-T (orthonormal columns)
+//   V      q x m      Yh^T L^-1 G^T
+//   L11    q(q+1)/2   Cholesky factor of A Q^-1 A^T, packed lower          (replaces S_LU[:q,:q])
+//   dinv11 q
+//   r1     m          R 1
+//   scal   4          [0] = || G^T 1 ||_2
+//   T      m(m+1)/2   scratch: Cholesky factor of R + diag(1/d) when it does not fit in LDS
+#pragma once
+#include <cstddef>
+
+namespace qpx {
+
+#if defined(__HIPCC__)
+#define QPX_LAYOUT_HD __host__ __device__ inline
+#else
+#define QPX_LAYOUT_HD inline
+#endif
+
+QPX_LAYOUT_HD size_t tri(size_t i) { return i * (i + 1) / 2; }
+QPX_LAYOUT_HD size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+struct FacLayout {
+    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, total;
+};
+
+QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
+{
+    FacLayout f;
+    size_t o = 0;
+    f.L = o;      o += align4(tri(n));
+    f.dinvL = o;  o += align4(n);
+    f.Zp = o;     o += align4((size_t)n * m);
+    f.R = o;      o += align4(tri(m));
+    f.Yh = o;     o += align4((size_t)n * q);
+    f.V = o;      o += align4((size_t)q * m);
+    f.L11 = o;    o += align4(tri(q));
+    f.dinv11 = o; o += align4(q);
+    f.r1 = o;     o += align4(m);
+    f.scal = o;   o += 4;
+    f.T = o;      o += align4(tri(m));
+    f.total = o;
+    return f;
+}
+
+// per-QP status bits written by the kernels (device memory, int32)
+enum : int {
+    QPX_ST_Q_NOT_SPD = 1,     // Cholesky of Q broke down      -> RuntimeError('Q is not SPD.')
+    QPX_ST_A_RANK = 2,        // Cholesky of A Q^-1 A^T broke down (A row-rank deficient)
+    QPX_ST_KKT_BREAKDOWN = 4, // factor_kkt broke down during the IPM loop (best iterate returned)
+    QPX_ST_INACCURATE = 8,    // best residual > 1                 -> INACC_ERR warning
+    QPX_ST_MAXITER = 16,      // loop ended on maxIter
+    QPX_ST_NONFINITE = 32     // iterate went NaN/Inf (best iterate returned)
+};
+
+}  // namespace qpx

@@ -1,0 +1,71 @@
+// qpx_platform.h -- gfx950 (CDNA4) execution primitives used by the qpx kernels.
+//
+// The kernel bodies in qpx_kernels.h are written against this tiny vocabulary (wave64,
+// workgroup barrier, intra-wave LDS ordering point, wave shuffles).  The test tree carries a
+// second header of the same name (tests/emu/qpx_platform.h) that runs the SAME kernel bodies
+// on host threads so that indexing/logic can be checked without a GPU and under
+// ThreadSanitizer; that emulation is test infrastructure and is never linked into
+// libqpx_hip.so.
+#ifndef QPX_PLATFORM_H
+#define QPX_PLATFORM_H
+#include <hip/hip_runtime.h>
+
+#define QPX_DEV __device__ __forceinline__
+#define QPX_HD __host__ __device__ __forceinline__
+
+namespace qpx {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+struct Block {
+    int tid;  // thread index in the workgroup
+    int nt;   // workgroup size (multiple of 64)
+
+    QPX_DEV int lane() const { return tid & (kWave - 1); }
+    QPX_DEV int wave() const { return tid >> 6; }
+    QPX_DEV int nwaves() const { return nt >> 6; }
+
+    // workgroup barrier; LDS and global writes of the workgroup made before it are visible after
+    QPX_DEV void sync() const { __syncthreads(); }
+
+    // ordering point for LDS traffic between lanes of ONE wave.  A wave's DS instructions
+    // execute in issue order, so only the compiler must be kept from moving them.
+    QPX_DEV void wave_sync() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    QPX_DEV float shfl_xor(float v, int mask) const { return __shfl_xor(v, mask, kWave); }
+    QPX_DEV double shfl_xor(double v, int mask) const { return __shfl_xor(v, mask, kWave); }
+    QPX_DEV int shfl_xor(int v, int mask) const { return __shfl_xor(v, mask, kWave); }
+
+    // value of `v` held by lane `src` (src must be wave-uniform): v_readlane, no LDS traffic
+    QPX_DEV float bcast(float v, int src) const
+    {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+    }
+    QPX_DEV double bcast(double v, int src) const
+    {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+        const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    QPX_DEV int bcast(int v, int src) const { return __builtin_amdgcn_readlane(v, src); }
+};
+
+template <class T> QPX_DEV T fma_(T a, T b, T c);
+template <> QPX_DEV float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> QPX_DEV double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+QPX_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
+QPX_DEV double sqrt_(double x) { return __builtin_sqrt(x); }
+QPX_DEV float abs_(float x) { return __builtin_fabsf(x); }
+QPX_DEV double abs_(double x) { return __builtin_fabs(x); }
+QPX_DEV bool finite_(float x) { return __builtin_isfinite(x); }
+QPX_DEV bool finite_(double x) { return __builtin_isfinite(x); }
+
+}  // namespace qpx
+#endif  // QPX_PLATFORM_H

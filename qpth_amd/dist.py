@@ -1,0 +1,58 @@
+"""Batch sharding across the GPUs of one node (one process per GPU, torch.distributed with
+backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+
+QPs never interact, so the data path needs no collective: every rank solves
+its contiguous slice of the batch.  Communication exists only at the edges:
+  * all_gather of zhat (and lam/nu/slacks on request) when a caller wants full-batch outputs;
+  * all_reduce(SUM) of the gradients of batch-SHARED parameters, scaled so that the result is
+    the reference's `.mean(0)` over the GLOBAL batch (qpth/qp.py:159-177).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(nBatch, rank, world):
+    """contiguous slice [lo, hi) of a batch of nBatch owned by `rank`"""
+    base, rem = divmod(nBatch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_params(params, nBatch, rank, world, ndims=(3, 2, 3, 2, 3, 2)):
+    """slice batched parameters, pass un-batched / empty ones through (qpth/util.py:44-50)"""
+    lo, hi = shard_bounds(nBatch, rank, world)
+    out = []
+    for X, nd in zip(params, ndims):
+        out.append(X[lo:hi] if (X.nelement() > 0 and X.dim() == nd) else X)
+    return out
+
+
+def gather_batch(local, nBatch, group=None):
+    """all_gather row blocks of possibly different length into the full (nBatch, ...) tensor"""
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(nBatch, r, world) for r in range(world)]
+    maxlen = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((maxlen,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([bf[:hi - lo] for bf, (lo, hi) in zip(bufs, sizes)], 0)
+
+
+def reduce_shared_grad(local_mean_grad, n_local, nBatch, group=None):
+    """Gradient of a batch-shared parameter: ranks hold the mean over their own slice; the
+    global `.mean(0)` is sum_r (n_r / nBatch) * mean_r."""
+    g = local_mean_grad * (float(n_local) / float(nBatch))
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    return g
+
+
+def solve_sharded(qp_function, Q, p, G, h, A, b, nBatch, gather=True, group=None):
+    """Solve the global batch data-parallel: this rank's slice through `qp_function`
+    (a QPFunction(...) callable); returns the local zhat and, if gather, the full one."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lQ, lp, lG, lh, lA, lb = shard_params([Q, p, G, h, A, b], nBatch, rank, world)
+    z_local = qp_function(lQ, lp, lG, lh, lA, lb)
+    if not gather:
+        return z_local, None
+    return z_local, gather_batch(z_local.detach(), nBatch, group)

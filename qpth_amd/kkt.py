@@ -1,0 +1,146 @@
+"""Device-resident KKT factor state of one batch and the launches that use it.
+
+`KKTFactors` is what the reference keeps as (Q_LU, S_LU, R) on ctx between forward and
+backward (qpth/qp.py:93,150-155): here one HBM blob per QP written by qpx_pre_factor
+(layout: qpth_amd/csrc/qpx_layout.h) plus the recorded `d` of factor_kkt.  When Q, G and A
+are all shared by the batch (un-batched parameters, qpth/util.py:44-50) the blob is built
+once and every workgroup reads the same copy.
+"""
+import torch
+
+from . import _lib
+
+_STALL_POLICY = None     # None = automatic (reference counter for B == 1, floor rule otherwise)
+
+
+def set_stall_policy(policy):
+    """Override how `notImprovedLim` is applied per QP (see include/qpx.h); None = automatic."""
+    global _STALL_POLICY
+    assert policy in (None, _lib.STALL_OFF, _lib.STALL_REFERENCE, _lib.STALL_FLOOR)
+    _STALL_POLICY = policy
+
+
+def default_stall_policy(B):
+    if _STALL_POLICY is not None:
+        return _STALL_POLICY
+    return _lib.STALL_REFERENCE if B == 1 else _lib.STALL_FLOOR
+
+
+class IpmResult:
+    __slots__ = ("zhat", "nu", "lam", "slacks", "iters", "status", "best_resid", "trace")
+
+
+def _batch_of(*params3):
+    for X in params3:
+        if X is not None and X.nelement() > 0 and X.dim() == 3:
+            return X.size(0)
+    return 1
+
+
+def _is_shared(X, B):
+    if X is None or X.nelement() == 0:
+        return True
+    return X.dim() == 2 or X.stride(0) == 0 or (B > 1 and X.size(0) == 1)
+
+
+class KKTFactors:
+    def __init__(self):
+        self.d = None
+
+    @classmethod
+    def build(cls, Q, G, A, nBatch=None):
+        """pre_factor_kkt(Q, G, A)   (batch.py:375-429); enqueues one kernel, no host sync."""
+        self = cls()
+        B = nBatch if nBatch is not None else _batch_of(Q, G, A)
+        self.B = B
+        self.n = Q.size(-1)
+        self.m = G.size(-2)
+        self.q = A.size(-2) if (A is not None and A.nelement() > 0) else 0
+        if G.size(-1) != self.n or Q.size(-2) != self.n or (self.q and A.size(-1) != self.n):
+            raise RuntimeError("qpth_amd: inconsistent QP sizes Q%s G%s A%s" % (
+                tuple(Q.shape), tuple(G.shape), tuple(A.shape) if A is not None else ()))
+        self.lib = _lib.backend_for(Q)
+        self.dtype, self.device = Q.dtype, Q.device
+        self.elems = self.lib.factor_elems(self.n, self.m, self.q)
+        code = _lib.QPX_F64 if Q.dtype == torch.float64 else _lib.QPX_F32
+        fits = bool(self.lib.dll.qpx_fits_lds(code, self.n, self.m, self.q))
+        self.shared = B > 1 and fits and _is_shared(Q, B) and _is_shared(G, B) and _is_shared(A, B)
+        nblob = 1 if self.shared else B
+        self.sfac = 0 if self.shared else self.elems
+        self.blob = torch.empty(nblob * self.elems, dtype=Q.dtype, device=Q.device)
+        self.status = torch.zeros(B, dtype=torch.int32, device=Q.device)
+        self.lib.pre_factor(nblob, self.n, self.m, self.q, Q, G, A if self.q else None, self.blob, self.status)
+        if self.shared:
+            self.status[1:] = self.status[0]
+        return self
+
+    # -- error surface of pre_factor_kkt / QPFunction (qp.py:81-85, batch.py:379-386) ------
+    def raise_on_failure(self, check_Q_spd=False):
+        st = int(torch.max(self.status & (_lib.ST_Q_NOT_SPD | _lib.ST_A_RANK)).item())
+        if st & _lib.ST_Q_NOT_SPD:
+            if check_Q_spd:
+                raise RuntimeError('Q is not SPD.')
+            raise RuntimeError("""
+qpth Error: Cannot perform LU factorization on Q.
+Please make sure that your Q matrix is PSD and has
+a non-zero diagonal.
+""")
+        if st & _lib.ST_A_RANK:
+            raise RuntimeError("qpth_amd Error: A Q^-1 A^T is not positive definite; "
+                               "the equality constraints must have full row rank.")
+
+    def _vec(self, X, k):
+        """dense (B,k) contiguous tensor or None"""
+        if X is None or X.nelement() == 0 or k == 0:
+            return None
+        if X.dim() == 1:
+            X = X.unsqueeze(0).expand(self.B, k)
+        return X.contiguous()
+
+    # -- forward (batch.py:47-207) -------------------------------------------------------
+    def ipm(self, p, h, b, eps=1e-12, maxIter=20, notImprovedLim=3, stall_policy=None, want_trace=False):
+        B, n, m, q = self.B, self.n, self.m, self.q
+        dt, dev = self.dtype, self.device
+        r = IpmResult()
+        r.zhat = torch.empty(B, n, dtype=dt, device=dev)
+        r.nu = torch.empty(B, q, dtype=dt, device=dev)
+        r.lam = torch.empty(B, m, dtype=dt, device=dev)
+        r.slacks = torch.empty(B, m, dtype=dt, device=dev)
+        r.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        r.best_resid = torch.empty(B, dtype=dt, device=dev)
+        r.trace = torch.full((maxIter, B, 3), float('nan'), dtype=dt, device=dev) if want_trace else None
+        r.status = self.status
+        if stall_policy is None:
+            stall_policy = default_stall_policy(B)
+        self.lib.ipm(B, n, m, q, p, h, b if q else None, self.blob, self.sfac, eps, maxIter, notImprovedLim,
+                     stall_policy, r.zhat, r.nu if q else None, r.lam, r.slacks, r.iters, self.status,
+                     r.best_resid, r.trace)
+        return r
+
+    # -- factor_kkt + solve_kkt (batch.py:435-470, 349-372) ----------------------------------
+    def solve_kkt(self, d, rx, rs, rz, ry):
+        B, n, m, q = self.B, self.n, self.m, self.q
+        dt, dev = self.dtype, self.device
+        d = self._vec(d, m)
+        dx = torch.empty(B, n, dtype=dt, device=dev)
+        ds = torch.empty(B, m, dtype=dt, device=dev)
+        dz = torch.empty(B, m, dtype=dt, device=dev)
+        dy = torch.empty(B, q, dtype=dt, device=dev) if q else None
+        self.lib.factor_solve_kkt(B, n, m, q, self.blob, self.sfac, d, self._vec(rx, n), self._vec(rs, m),
+                                  self._vec(rz, m), self._vec(ry, q), dx, ds, dz, dy, self.status)
+        return dx, ds, dz, dy
+
+    # -- QPFunctionFn.backward (qp.py:127-182), per-QP gradients ---------------------------------
+    def backward(self, zhat, lam, slacks, nu, dl_dz):
+        B, n, m, q = self.B, self.n, self.m, self.q
+        dt, dev = self.dtype, self.device
+        dQ = torch.empty(B, n, n, dtype=dt, device=dev)
+        dp = torch.empty(B, n, dtype=dt, device=dev)
+        dG = torch.empty(B, m, n, dtype=dt, device=dev)
+        dh = torch.empty(B, m, dtype=dt, device=dev)
+        dA = torch.empty(B, q, n, dtype=dt, device=dev) if q else None
+        db = torch.empty(B, q, dtype=dt, device=dev) if q else None
+        self.lib.backward(B, n, m, q, self.blob, self.sfac, self._vec(zhat, n), self._vec(lam, m),
+                          self._vec(slacks, m), self._vec(nu, q), self._vec(dl_dz, n),
+                          dQ, dp, dG, dh, dA, db, self.status)
+        return dQ, dp, dG, dh, dA, db

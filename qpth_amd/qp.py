@@ -1,0 +1,119 @@
+"""The autograd surface of the reference, unchanged: qpth/qp.py:13-183.
+
+    QPFunction(eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20,
+               solver=QPSolvers.PDIPM_BATCHED, check_Q_spd=True)(Q, p, G, h, A, b) -> zhat (nBatch, nz)
+
+solves a batch of QPs  z* = argmin 1/2 z'Qz + p'z  s.t. Gz <= h, Az = b  and is differentiable
+in all six parameters.  Any subset of the parameters may be un-batched; an empty tensor
+means "no such constraint" (qp.py:58-61).  The forward runs two HIP kernels
+(pre_factor_kkt, PDIPM loop), the backward one (factor_kkt + solve_kkt + gradient outer
+products); state crosses from forward to backward on ctx exactly as in the reference.
+"""
+from enum import Enum
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .kkt import KKTFactors
+from .solvers.pdipm import batch as pdipm_b
+from .util import expandParam, extract_nBatch
+
+
+class QPSolvers(Enum):
+    PDIPM_BATCHED = 1
+    CVXPY = 2
+
+
+def _print_trace(res):
+    tr = res.trace.cpu()
+    iters = res.iters.cpu()
+    for i in range(int(iters.max().item())):
+        row = tr[i][iters > i]
+        print('iter: {}, pri_resid: {:.5e}, dual_resid: {:.5e}, mu: {:.5e}'.format(
+            i, row[:, 0].mean(), row[:, 1].mean(), row[:, 2].mean()))
+
+
+def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
+               maxIter=20, solver=QPSolvers.PDIPM_BATCHED,
+               check_Q_spd=True):
+    class QPFunctionFn(Function):
+        @staticmethod
+        def forward(ctx, Q_, p_, G_, h_, A_, b_):
+            nBatch = extract_nBatch(Q_, p_, G_, h_, A_, b_)
+            Q, _ = expandParam(Q_, nBatch, 3)
+            p, _ = expandParam(p_, nBatch, 2)
+            G, _ = expandParam(G_, nBatch, 3)
+            h, _ = expandParam(h_, nBatch, 2)
+            A, _ = expandParam(A_, nBatch, 3)
+            b, _ = expandParam(b_, nBatch, 2)
+
+            _, nineq, nz = G.size()
+            neq = A.size(1) if A.nelement() > 0 else 0
+            assert(neq > 0 or nineq > 0)
+            ctx.neq, ctx.nineq, ctx.nz = neq, nineq, nz
+
+            if solver == QPSolvers.PDIPM_BATCHED:
+                fac = KKTFactors.build(Q, G, A, nBatch)            # qp.py:93
+                res = fac.ipm(p, h, b, eps, maxIter, notImprovedLim,
+                              want_trace=(verbose == 1))             # qp.py:94-96
+                # one small read-back: the reference raises here too (qp.py:81-85, batch.py:379-386)
+                fac.raise_on_failure(check_Q_spd)
+                if verbose == 1:
+                    _print_trace(res)
+                if verbose >= 0:
+                    if not bool((res.best_resid <= 1.).all().item()):
+                        print(pdipm_b.INACC_ERR)                     # batch.py:141-142,205-206
+                ctx.fac = fac
+                zhats, ctx.nus, ctx.lams, ctx.slacks = res.zhat, res.nu, res.lam, res.slacks
+            elif solver == QPSolvers.CVXPY:
+                # forward by an external CPU solver, backward by the HIP kernels (qp.py:97-120,142-143)
+                from .solvers import cvxpy as cvx_solver
+                zhats, ctx.nus, ctx.lams, ctx.slacks = cvx_solver.forward_batch(Q, p, G, h, A, b, neq)
+                ctx.fac = None
+            else:
+                assert False
+
+            ctx.save_for_backward(zhats, Q_, p_, G_, h_, A_, b_)
+            return zhats
+
+        @staticmethod
+        def backward(ctx, dl_dzhat):
+            zhats, Q, p, G, h, A, b = ctx.saved_tensors
+            nBatch = extract_nBatch(Q, p, G, h, A, b)
+            Q, Q_e = expandParam(Q, nBatch, 3)
+            p, p_e = expandParam(p, nBatch, 2)
+            G, G_e = expandParam(G, nBatch, 3)
+            h, h_e = expandParam(h, nBatch, 2)
+            A, A_e = expandParam(A, nBatch, 3)
+            b, b_e = expandParam(b, nBatch, 2)
+            neq = ctx.neq
+
+            fac = ctx.fac
+            if fac is None:                                          # qp.py:142-143
+                fac = KKTFactors.build(Q, G, A, nBatch)
+                fac.raise_on_failure(check_Q_spd)
+
+            # d = clamp(lams)/clamp(slacks), factor_kkt, solve_kkt(dl_dzhat, 0, 0, 0) and the
+            # outer products (qp.py:148-173) happen inside one kernel
+            dQs, dps, dGs, dhs, dAs, dbs = fac.backward(zhats, ctx.lams, ctx.slacks, ctx.nus, dl_dzhat)
+
+            if G_e:
+                dGs = dGs.mean(0)
+            if h_e:
+                dhs = dhs.mean(0)
+            if neq > 0:
+                if A_e:
+                    dAs = dAs.mean(0)
+                if b_e:
+                    dbs = dbs.mean(0)
+            else:
+                dAs, dbs = None, None
+            if Q_e:
+                dQs = dQs.mean(0)
+            if p_e:
+                dps = dps.mean(0)
+
+            grads = (dQs, dps, dGs, dhs, dAs, dbs)
+            return grads
+    return QPFunctionFn.apply

@@ -1,0 +1,71 @@
+// tests/emu/qpx_platform.h -- HOST-THREAD EMULATION of qpth_amd/csrc/qpx_platform.h.
+//
+// TEST INFRASTRUCTURE ONLY.  (Shares the include guard QPX_PLATFORM_H with the HIP header so that
+// including this file first makes qpx_kernels.h compile against the emulation.)  It lets the *same* kernel bodies (qpth_amd/csrc/qpx_kernels.h)
+// run on CPU threads -- one pthread per GPU thread, pthread barriers for __syncthreads and
+// for the lock-step exchange behind wave shuffles -- so that indexing, control flow and
+// barrier placement can be checked in the GPU-less build container (and under
+// ThreadSanitizer).  It is compiled into tests/emu/_build/libqpx_emu.so, which only tests
+// load; libqpx_hip.so never contains it and the qpth_amd package never falls back to it.
+#ifndef QPX_PLATFORM_H
+#define QPX_PLATFORM_H
+#include <pthread.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+
+#define QPX_DEV inline
+#define QPX_HD inline
+
+namespace qpx {
+
+constexpr int kWave = 64;
+
+struct EmuShared {
+    pthread_barrier_t block_bar;   // all threads of the workgroup
+    pthread_barrier_t* wave_bar;   // one per wave
+    unsigned long long* xchg;      // one 8-byte exchange slot per thread
+};
+
+struct Block {
+    int tid;
+    int nt;
+    EmuShared* sh;
+
+    int lane() const { return tid & (kWave - 1); }
+    int wave() const { return tid >> 6; }
+    int nwaves() const { return nt >> 6; }
+    void sync() const { pthread_barrier_wait(&sh->block_bar); }
+    void wave_sync() const { pthread_barrier_wait(&sh->wave_bar[wave()]); }
+
+    template <class T> T exchange(T v, int src_lane) const
+    {
+        unsigned long long bits = 0;
+        std::memcpy(&bits, &v, sizeof(T));
+        sh->xchg[tid] = bits;
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        bits = sh->xchg[(tid & ~(kWave - 1)) | (src_lane & (kWave - 1))];
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        T r;
+        std::memcpy(&r, &bits, sizeof(T));
+        return r;
+    }
+    float shfl_xor(float v, int mask) const { return exchange(v, lane() ^ mask); }
+    double shfl_xor(double v, int mask) const { return exchange(v, lane() ^ mask); }
+    int shfl_xor(int v, int mask) const { return exchange(v, lane() ^ mask); }
+    float bcast(float v, int src) const { return exchange(v, src); }
+    double bcast(double v, int src) const { return exchange(v, src); }
+    int bcast(int v, int src) const { return exchange(v, src); }
+};
+
+template <class T> inline T fma_(T a, T b, T c) { return std::fma(a, b, c); }
+inline float sqrt_(float x) { return std::sqrt(x); }
+inline double sqrt_(double x) { return std::sqrt(x); }
+inline float abs_(float x) { return std::fabs(x); }
+inline double abs_(double x) { return std::fabs(x); }
+inline bool finite_(float x) { return std::isfinite(x); }
+inline bool finite_(double x) { return std::isfinite(x); }
+
+}  // namespace qpx
+#endif  // QPX_PLATFORM_H

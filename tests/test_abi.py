@@ -1,0 +1,72 @@
+"""The C-ABI boundary: libqpx_hip.so loads and exports exactly what include/qpx.h declares
+(no compute calls -- those need a GPU and live in the -m gpu tests)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "qpx.h")
+HIP_SO = os.path.join(ROOT, "qpth_amd", "libqpx_hip.so")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qpx_[a-z_0-9]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()          # hipcc cross-compiles gfx950 without a GPU
+    return HIP_SO
+
+
+def test_header_and_binding_agree():
+    from qpth_amd import _lib
+    assert sorted(_lib.ABI_SYMBOLS) == declared_symbols()
+
+
+def test_hip_library_exports_every_declared_symbol(built):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built]).decode()
+    exported = set(re.findall(r" T (qpx_[a-z_0-9]+)", out))
+    assert set(declared_symbols()) <= exported, set(declared_symbols()) - exported
+
+
+def test_hip_library_loads_and_answers_metadata(built):
+    from qpth_amd import _lib
+    lib = _lib.QpxLib(built)
+    assert lib.dll.qpx_abi_version() == 1
+    assert lib.dll.qpx_max_dim() == 512
+    assert lib.factor_elems(100, 100, 0) > 100 * 100
+    assert lib.dll.qpx_fits_lds(_lib.QPX_F64, 100, 100, 0) == 1      # C2 runs LDS-resident in f64
+    assert lib.dll.qpx_fits_lds(_lib.QPX_F64, 500, 500, 0) == 0      # C4 does not
+    assert b"not supported" in lib.dll.qpx_strerror(-2)
+
+
+def test_hip_library_contains_gfx950_code(built):
+    blob = open(built, "rb").read()
+    assert b"hipv4-amdgcn-amd-amdhsa--gfx950" in blob          # the fat binary targets MI355X
+    assert b"gfx942" not in blob and b"sm_" not in blob          # ... and nothing else
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    from qpth_amd import _lib
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.QpxLib(str(tmp_path / "libqpx_hip.so"))
+
+
+def test_cpu_tensors_are_refused():
+    """The product path never falls back to a CPU implementation."""
+    import torch
+    from qpth_amd.qp import QPFunction
+    Q = torch.eye(3, dtype=torch.float64).unsqueeze(0)
+    p = torch.zeros(1, 3, dtype=torch.float64)
+    G = torch.ones(1, 2, 3, dtype=torch.float64)
+    h = torch.ones(1, 2, dtype=torch.float64)
+    e = torch.empty(0, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        QPFunction(verbose=-1)(Q, p, G, h, e, e)
