@@ -1,0 +1,93 @@
+// qpx_hip_kernels.hip -- the gfx950 kernels and their launchers.
+//
+// One workgroup (256 threads = 4 wave64) per QP; the KKT blocks of that QP live in LDS
+// (dynamic, up to the full 160 KiB) for the whole kernel, or in the HBM factor blob when they
+// do not fit.  Kernels are stream-ordered, allocate nothing and never synchronise the host.
+//
+// Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm, 3 = kkt/backward.
+#include <hip/hip_runtime.h>
+
+#include "../../include/qpx.h"
+#include "qpx_launch.h"
+
+#ifndef QPX_TU_KERNEL
+#error "QPX_TU_KERNEL (1|2|3) and QPX_TU_REAL (float|double) must be defined"
+#endif
+
+namespace qpx {
+
+// Dynamic LDS above 64 KiB has to be opted into once per kernel symbol.
+template <class K> static int allow_big_lds(K kernel, size_t bytes, bool& done)
+{
+    if (bytes <= 64 * 1024 || done) return QPX_OK;
+    done = true;   // idempotent, so a benign race between host threads is harmless
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kMaxLdsBytes) != hipSuccess)
+        return QPX_ERR_LAUNCH;
+    return QPX_OK;
+}
+
+#if QPX_TU_KERNEL == 1
+template <class T, int NS, bool kLds>
+__global__ __launch_bounds__(kThreads) void k_prefactor(PrefactorArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    prefactor_body<T, NS, kLds>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NS, bool kLds>
+int launch_prefactor(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_prefactor<T, NS, kLds>;
+    static bool big_lds_enabled = false;   // one flag per kernel instantiation
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INST(NS, L) \
+    template int launch_prefactor<QPX_TU_REAL, NS, L>(const PrefactorArgs<QPX_TU_REAL>&, size_t, void*);
+#elif QPX_TU_KERNEL == 2
+template <class T, int NS, bool kLds>
+__global__ __launch_bounds__(kThreads) void k_ipm(IpmArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    ipm_body<T, NS, kLds>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NS, bool kLds>
+int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_ipm<T, NS, kLds>;
+    static bool big_lds_enabled = false;   // one flag per kernel instantiation
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INST(NS, L) \
+    template int launch_ipm<QPX_TU_REAL, NS, L>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
+#elif QPX_TU_KERNEL == 3
+template <class T, int NS, bool kLds, bool kBw>
+__global__ __launch_bounds__(kThreads) void k_kkt(KktArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    kkt_body<T, NS, kLds, kBw>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NS, bool kLds, bool kBw>
+int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_kkt<T, NS, kLds, kBw>;
+    static bool big_lds_enabled = false;   // one flag per kernel instantiation
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INST(NS, L)                                                                              \
+    template int launch_kkt<QPX_TU_REAL, NS, L, false>(const KktArgs<QPX_TU_REAL>&, size_t, void*); \
+    template int launch_kkt<QPX_TU_REAL, NS, L, true>(const KktArgs<QPX_TU_REAL>&, size_t, void*);
+#endif
+
+QPX_INST(1, true) QPX_INST(1, false) QPX_INST(2, true) QPX_INST(2, false)
+QPX_INST(4, true) QPX_INST(4, false) QPX_INST(8, true) QPX_INST(8, false)
+
+}  // namespace qpx

@@ -1,0 +1,26 @@
+// qpx_launch.h -- launcher declarations shared by the kernel translation units and the C ABI.
+// Each (kernel, dtype) pair is compiled in its own translation unit (qpx_hip_kernels.hip with
+// -DQPX_TU_KERNEL=... -DQPX_TU_REAL=...) so the build parallelises; the definitions live there.
+#pragma once
+#include <cstddef>
+#include <type_traits>
+
+#include "qpx_kernels.h"
+
+namespace qpx {
+
+template <int V> using Int = std::integral_constant<int, V>;
+template <bool V> using Bool = std::integral_constant<bool, V>;
+
+constexpr int kThreads = 256;   // one workgroup = 4 wave64 per QP
+
+inline size_t lds_budget_bytes() { return kMaxLdsBytes; }
+
+template <class T, int NS, bool kLds>
+int launch_prefactor(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream);
+template <class T, int NS, bool kLds>
+int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
+template <class T, int NS, bool kLds, bool kBw>
+int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream);
+
+}  // namespace qpx

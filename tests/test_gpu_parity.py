@@ -1,0 +1,273 @@
+"""-m gpu: parity of the HIP path (through the C ABI, on a real MI355X) with the reference.
+
+Three kinds of evidence, as the brief asks:
+  1. golden vectors produced by the reference itself (tests/golden, make_golden.py);
+  2. the oracle (CPU restatement, pinned to those vectors) on seeded inputs at sizes it
+     finishes in seconds -- BASELINE.json configs C1..C3 and a C5 slice;
+  3. size-independent properties at BASELINE.json's full sizes: KKT optimality of the returned
+     (zhat, lam, nu, slacks), gradient consistency with finite differences of the solver, batch
+     permutation equivariance, idempotence of a warm re-solve.
+Tolerances are written where they are used; f64: 1e-6 relative unless noted (north star: 1e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+import problems
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from qpth_amd import _lib
+    _lib.hip()                              # the HIP extension must be the thing that runs
+    assert _lib._TEST_BACKEND is None
+    return torch.device("cuda:0")
+
+
+def to_dev(arrs, dev, dtype=torch.float64, grad=True):
+    out = []
+    for x in arrs:
+        x = np.asarray(x)
+        t = torch.tensor(x, dtype=dtype, device=dev) if x.size else torch.empty(0, dtype=dtype, device=dev)
+        if grad and t.nelement() > 0:
+            t.requires_grad_(True)
+        out.append(t)
+    return out
+
+
+def run_qpf(arrs, dl, dev, dtype=torch.float64, **kw):
+    from qpth_amd.qp import QPFunction
+    tq = to_dev(arrs, dev, dtype)
+    z = QPFunction(verbose=-1, **kw)(*tq)
+    z.backward(torch.tensor(np.asarray(dl), dtype=dtype, device=dev))
+    torch.cuda.synchronize()
+    return z.detach().cpu().numpy(), [t.grad.cpu().numpy() if t.grad is not None else None for t in tq]
+
+
+def golden_inputs(g, dtype=np.float64):
+    if "Q" in g:
+        return [g[k] for k in ("Q", "p", "G", "h", "A", "b")]
+    B, n, m, q, seed = [int(v) for v in g["shape"]]
+    return list(problems.prof_qp(B, n, m, q, seed, dtype))
+
+
+# ---------------------------------------------------------------- 1. golden vectors
+@pytest.mark.parametrize("name", ["dl_dp", "dl_dG", "dl_dh", "dl_dA", "dl_db"])
+def test_reference_gradient_problems(dev, name):
+    g = load_golden("grads_" + name)
+    z, grads = run_qpf(golden_inputs(g), g["dl_dz"], dev)
+    assert rel_err(z, g["zhat"]).max() < TOL
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g:
+            assert gr.shape == g[k].shape
+            assert np.abs(gr - g[k]).max() <= TOL * max(1.0, np.abs(g[k]).max()), k
+
+
+@pytest.mark.parametrize("name", ["c1_b8_n10_m5_f64", "c3s_b4_n20_m10_q4_f64", "c2s_b4_n100_m100_f64",
+                                  "c3s_b4_n100_m50_q10_f64", "c5s_b6_n64_m64_f64",
+                                  "broadcast_b5_n12_m9_q3", "unbatched_n12_m9_q3"])
+def test_golden_batches(dev, name):
+    g = load_golden(name)
+    z, grads = run_qpf(golden_inputs(g), g["dl_dz"], dev)
+    assert z.shape == g["zhat"].shape
+    assert rel_err(z, g["zhat"]).max() < TOL
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g:
+            assert gr.shape == g[k].shape, k
+            assert np.abs(gr - g[k]).max() <= 10 * TOL * max(1.0, np.abs(g[k]).max()), k
+
+
+def test_solver_entry_points_match_reference(dev):
+    """pre_factor_kkt / factor_kkt / solve_kkt / forward, the seam of qp.py:92-96,148-155."""
+    from qpth_amd.solvers.pdipm import batch as pdipm_b
+    g = load_golden("kkt_solver")
+    Q, p, G, h, A, b = to_dev([g[k] for k in ("Q", "p", "G", "h", "A", "b")], dev, grad=False)
+    Qe, Ae = Q.unsqueeze(0).expand(2, 5, 5), A.unsqueeze(0).expand(2, 3, 5)
+    d, rx, rs, rz, ry = to_dev([g[k] for k in ("d", "rx", "rs", "rz", "ry")], dev, grad=False)
+    Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(Qe, G, Ae)
+    pdipm_b.factor_kkt(S_LU, R, d)
+    outs = pdipm_b.solve_kkt(Q_LU, d, G, Ae, S_LU, rx, rs, rz, ry)
+    for mine, key in zip(outs, ("dx", "ds", "dz", "dy")):
+        assert np.allclose(mine.cpu().numpy(), g[key], rtol=1e-8, atol=1e-9), key
+    g = load_golden("c3s_b4_n20_m10_q4_f64")
+    Q, p, G, h, A, b = to_dev(golden_inputs(g), dev, grad=False)
+    Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(Q, G, A)
+    x, y, z, s = pdipm_b.forward(Q, p, G, h, A, b, Q_LU, S_LU, R, verbose=-1)
+    assert rel_err(x.cpu().numpy(), g["zhat"]).max() < TOL
+    assert rel_err(y.cpu().numpy(), g["nu"]).max() < TOL
+    assert rel_err(z.cpu().numpy(), g["lam"]).max() < 1e-5
+    assert np.abs(s.cpu().numpy() - g["slacks"]).max() < 1e-6
+
+
+def test_float32_is_as_close_to_f64_as_the_reference_f32(dev):
+    g32, g64 = load_golden("c1_b8_n10_m5_f32"), load_golden("c1_b8_n10_m5_f64")
+    z, _ = run_qpf(golden_inputs(g32), g32["dl_dz"], dev, dtype=torch.float32)
+    mine = rel_err(z, g64["zhat"]).max()
+    ref = rel_err(g32["zhat"], g64["zhat"]).max()
+    assert mine < max(10 * ref, 5e-4), (mine, ref)
+
+
+# ---------------------------------------------------------------- 2. oracle, seeded inputs
+@pytest.mark.parametrize("B,n,m,q,seed", [(8, 10, 5, 0, 3), (64, 100, 100, 0, 0), (64, 100, 50, 10, 1),
+                                           (128, 64, 64, 0, 2), (16, 33, 70, 7, 4), (32, 2, 40, 0, 5),
+                                           (3, 130, 90, 20, 6)])
+def test_against_oracle(dev, B, n, m, q, seed):
+    """z*, lam, nu, slacks and all gradients vs the oracle in reference (whole-batch) semantics."""
+    from oracle import qp_oracle as orc
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed)
+    dl = np.random.RandomState(seed).randn(B, n)
+    x, y, lam, s, grads, info = orc.qp_forward_backward(Q, p, G, h, A, b, dl_dz=dl)
+    z, mine = run_qpf([Q, p, G, h, A, b], dl, dev)
+    assert rel_err(z, x).max() < TOL
+    for a_, r_, k in zip(mine, grads, ("dQ", "dp", "dG", "dh", "dA", "db")):
+        if r_ is not None:
+            assert np.abs(a_ - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max()), k
+
+
+def test_duals_against_oracle(dev):
+    from oracle import qp_oracle as orc
+    from qpth_amd.kkt import KKTFactors
+    Q, p, G, h, A, b = problems.prof_qp(32, 100, 50, 10, 9)
+    x, y, lam, s, info = orc.OracleQP(Q, p, G, h, A, b).forward()
+    tQ, tp, tG, th, tA, tb = to_dev([Q, p, G, h, A, b], dev, grad=False)
+    fac = KKTFactors.build(tQ, tG, tA)
+    res = fac.ipm(tp, th, tb)
+    torch.cuda.synchronize()
+    assert int(res.status.max().item()) & 3 == 0
+    assert rel_err(res.zhat.cpu().numpy(), x).max() < TOL
+    assert rel_err(res.nu.cpu().numpy(), y).max() < TOL
+    assert rel_err(res.lam.cpu().numpy(), lam).max() < 1e-5
+    assert np.abs(res.slacks.cpu().numpy() - s).max() < 1e-6
+
+
+# ---------------------------------------------------------------- 3. properties at full size
+def kkt_residuals(Q, p, G, h, A, b, z, lam, nu, s):
+    """solver-free optimality measures: stationarity, primal feasibility,
+    dual feasibility, complementarity -- evaluated in torch on the device."""
+    rx = torch.einsum("bij,bj->bi", Q, z) + p + torch.einsum("bmi,bm->bi", G, lam)
+    if A.nelement():
+        rx = rx + torch.einsum("bqi,bq->bi", A, nu)
+        ry = torch.einsum("bqi,bi->bq", A, z) - b
+    else:
+        ry = torch.zeros(z.shape[0], 1, dtype=z.dtype, device=z.device)
+    gz = torch.einsum("bmi,bi->bm", G, z) - h
+    return (rx.norm(dim=1), torch.clamp(gz, min=0).norm(dim=1), ry.norm(dim=1),
+            torch.clamp(-lam, min=0).norm(dim=1), (lam * gz).abs().sum(1), (gz + s).norm(dim=1))
+
+
+@pytest.mark.parametrize("B,n,m,q", [(512, 100, 100, 0), (512, 100, 50, 10), (4096, 64, 64, 0)])
+def test_full_size_optimality(dev, B, n, m, q):
+    """BASELINE.json C2 / C3 / (a 4096-QP slab of) C5 at full per-QP size: every QP's answer
+    satisfies the KKT conditions to round-off scale (the reference reaches ~1e-12)."""
+    from qpth_amd.kkt import KKTFactors
+    arrs = problems.prof_qp(B, n, m, q, seed=0)
+    tQ, tp, tG, th, tA, tb = to_dev(arrs, dev, grad=False)
+    fac = KKTFactors.build(tQ, tG, tA)
+    res = fac.ipm(tp, th, tb)
+    torch.cuda.synchronize()
+    assert int(res.status.max().item()) & 7 == 0
+    stat, pinf, einf, dinf, comp, slk = kkt_residuals(tQ, tp, tG, th, tA, tb, res.zhat, res.lam, res.nu, res.slacks)
+    scale = (tp.norm(dim=1) + th.norm(dim=1)).max().item()
+    for name, v, tol in (("stationarity", stat, 1e-8), ("primal", pinf, 1e-8), ("equality", einf, 1e-8),
+                         ("dual sign", dinf, 1e-12), ("complementarity", comp, 1e-8), ("slack", slk, 1e-8)):
+        assert v.max().item() < tol * scale, (name, v.max().item(), scale)
+    assert res.iters.max().item() <= 20 and res.iters.float().mean().item() < 18
+
+
+def test_full_size_matches_oracle_c2(dev):
+    """The headline config (batch=512 nz=100 nineq=100) against the oracle: ~1 s of CPU."""
+    from oracle import qp_oracle as orc
+    Q, p, G, h, A, b = problems.prof_qp(512, 100, 100, 0, 0)
+    dl = np.ones((512, 100))
+    x, y, lam, s, grads, info = orc.qp_forward_backward(Q, p, G, h, A, b, dl_dz=dl)
+    z, mine = run_qpf([Q, p, G, h, A, b], dl, dev)
+    assert rel_err(z, x).max() < TOL                    # north star: 1e-4
+    assert np.abs(mine[1] - grads[1]).max() <= 1e-5 * np.abs(grads[1]).max()
+    assert np.abs(mine[0] - grads[0]).max() <= 1e-5 * np.abs(grads[0]).max()
+
+
+def test_batch_permutation_equivariance(dev):
+    """QPs are independent units: permuting the batch permutes the answers bit for bit."""
+    from qpth_amd.kkt import KKTFactors
+    arrs = problems.prof_qp(96, 40, 30, 5, seed=11)
+    tq = to_dev(arrs, dev, grad=False)
+    perm = torch.randperm(96, device=dev)
+    fac = KKTFactors.build(tq[0], tq[2], tq[4])
+    r0 = fac.ipm(tq[1], tq[3], tq[5])
+    fac1 = KKTFactors.build(tq[0][perm], tq[2][perm], tq[4][perm])
+    r1 = fac1.ipm(tq[1][perm], tq[3][perm], tq[5][perm])
+    assert torch.equal(r0.zhat[perm], r1.zhat)
+    assert torch.equal(r0.lam[perm], r1.lam)
+
+
+def test_gradients_match_finite_differences(dev):
+    """central differences of 1/2||zhat - t||^2 through the HIP forward vs the HIP backward
+    (the replacement for the reference's cvxpy+numdifftools checks)."""
+    from qpth_amd.qp import QPFunction
+    Q, p, G, h, A, b = problems.random_dense_qp(1, 8, 6, 2, seed=3)
+    tgt = np.random.RandomState(0).randn(1, 8)
+
+    def loss(params):
+        t = to_dev(params, dev, grad=False)
+        z = QPFunction(verbose=-1, eps=1e-14)(*t)
+        return 0.5 * float(((z - torch.tensor(tgt, device=dev)) ** 2).sum().item())
+
+    tq = to_dev([Q, p, G, h, A, b], dev)
+    z = QPFunction(verbose=-1, eps=1e-14)(*tq)
+    z.backward(z.detach() - torch.tensor(tgt, device=dev))
+    base = [Q, p, G, h, A, b]
+    eps = 1e-6
+    for idx, name in ((1, "dp"), (3, "dh"), (5, "db"), (2, "dG"), (4, "dA")):
+        g = tq[idx].grad.cpu().numpy()
+        fd = np.zeros_like(base[idx])
+        it = np.nditer(base[idx], flags=["multi_index"])
+        for _ in it:
+            mi = it.multi_index
+            plus = [x.copy() for x in base]; plus[idx][mi] += eps
+            minus = [x.copy() for x in base]; minus[idx][mi] -= eps
+            fd[mi] = (loss(plus) - loss(minus)) / (2 * eps)
+        assert np.abs(fd - g).max() < 1e-5 * max(1.0, np.abs(g).max()), name
+
+
+# ---------------------------------------------------------------- edge cases
+def test_edge_cases(dev):
+    from qpth_amd.qp import QPFunction
+    e = torch.empty(0, dtype=torch.float64, device=dev)
+    # nineq = 1, nz = 1
+    z = QPFunction(verbose=-1)(torch.ones(1, 1, 1, dtype=torch.float64, device=dev),
+                               torch.tensor([[-2.0]], dtype=torch.float64, device=dev),
+                               torch.ones(1, 1, 1, dtype=torch.float64, device=dev),
+                               torch.tensor([[1.0]], dtype=torch.float64, device=dev), e, e)
+    assert abs(z.item() - 1.0) < 1e-8                        # min 1/2 z^2 - 2z s.t. z <= 1
+    # inactive constraints only: z* = -Q^-1 p
+    Q, p, G, h, A, b = problems.random_dense_qp(4, 6, 3, 0, seed=1)
+    h = h + 1e3
+    tq = to_dev([Q, p, G, h, A, b], dev, grad=False)
+    z = QPFunction(verbose=-1)(*tq)
+    ref = -np.linalg.solve(Q, p[..., None])[..., 0]
+    assert rel_err(z.cpu().numpy(), ref).max() < 1e-8
+    # not SPD
+    with pytest.raises(RuntimeError, match="Q is not SPD."):
+        QPFunction(verbose=-1)(-torch.eye(3, dtype=torch.float64, device=dev).unsqueeze(0), tq[1][:1, :3],
+                               tq[2][:1, :, :3], tq[3][:1], e, e)
+    # size beyond this build
+    with pytest.raises(RuntimeError, match="not supported"):
+        QPFunction(verbose=-1)(torch.eye(600, dtype=torch.float64, device=dev).unsqueeze(0),
+                               torch.zeros(1, 600, dtype=torch.float64, device=dev),
+                               torch.ones(1, 1, 600, dtype=torch.float64, device=dev),
+                               torch.ones(1, 1, dtype=torch.float64, device=dev), e, e)
+
+
+def test_large_qp_hbm_resident_path(dev):
+    """nz = nineq = 200 (f64) exceeds 160 KiB of LDS: matrices are worked on in the HBM blob."""
+    from oracle import qp_oracle as orc
+    Q, p, G, h, A, b = problems.prof_qp(4, 200, 200, 0, 3)
+    x, y, lam, s, info = orc.OracleQP(Q, p, G, h, A, b).forward()
+    z, _ = run_qpf([Q, p, G, h, A, b], np.ones((4, 200)), dev)
+    assert rel_err(z, x).max() < TOL
