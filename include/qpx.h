@@ -81,6 +81,11 @@ size_t qpx_factor_elems(int n, int m, int q);
 int qpx_max_dim(void);
 int qpx_fits_lds(int dtype, int n, int m, int q);
 
+/* tuning/A-B knob: which PDIPM kernel qpx_ipm launches.  0 (default) = automatic: one wave64
+ * per QP with the m x m matrix in registers when nineq <= 104 and nz <= 128, else one
+ * 256-thread workgroup per QP; 1 = always the workgroup kernel.  Returns the previous value. */
+int qpx_set_ipm_variant(int variant);
+
 /* pre_factor_kkt(Q, G, A) */
 int qpx_pre_factor(int dtype, int B, int n, int m, int q,
                    const void* Q, int64_t sQ, const void* G, int64_t sG, const void* A, int64_t sA,

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "qpx_factor_elems": (ctypes.c_size_t, [_i, _i, _i]),
     "qpx_max_dim": (_i, []),
     "qpx_fits_lds": (_i, [_i, _i, _i, _i]),
+    "qpx_set_ipm_variant": (_i, [_i]),
     "qpx_pre_factor": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "qpx_ipm": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _d, _i, _i, _i,
                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -4,7 +4,8 @@
 // (dynamic, up to the full 160 KiB) for the whole kernel, or in the HBM factor blob when they
 // do not fit.  Kernels are stream-ordered, allocate nothing and never synchronise the host.
 //
-// Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm, 3 = kkt/backward.
+// Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm (workgroup per QP),
+// 3 = kkt/backward, 4 = ipm (wave per QP).
 #include <hip/hip_runtime.h>
 
 #include "../../include/qpx.h"
@@ -85,9 +86,31 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream)
 #define QPX_INST(NS, L)                                                                              \
     template int launch_kkt<QPX_TU_REAL, NS, L, false>(const KktArgs<QPX_TU_REAL>&, size_t, void*); \
     template int launch_kkt<QPX_TU_REAL, NS, L, true>(const KktArgs<QPX_TU_REAL>&, size_t, void*);
+#elif QPX_TU_KERNEL == 4
+template <class T, int NB, int NS>
+__global__ __launch_bounds__(kWave) void k_ipm_wave(IpmArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    ipm_wave_body<T, NB, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NB, int NS>
+int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_ipm_wave<T, NB, NS>;
+    static bool big_lds_enabled = false;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kWave), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTW(NB, NS) \
+    template int launch_ipm_wave<QPX_TU_REAL, NB, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
+QPX_INSTW(2, 1) QPX_INSTW(2, 2) QPX_INSTW(4, 1) QPX_INSTW(4, 2) QPX_INSTW(8, 1) QPX_INSTW(8, 2) QPX_INSTW(13, 2)
 #endif
 
+#if QPX_TU_KERNEL != 4
 QPX_INST(1, true) QPX_INST(1, false) QPX_INST(2, true) QPX_INST(2, false)
 QPX_INST(4, true) QPX_INST(4, false) QPX_INST(8, true) QPX_INST(8, false)
+#endif
 
 }  // namespace qpx

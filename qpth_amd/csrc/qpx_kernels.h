@@ -20,6 +20,18 @@
 #include "qpx_layout.h"
 #include "qpx_platform.h"
 
+// Phase timers of the profiling build (-DQPX_PROFILE, scripts/prof_phases.py): thread 0 of every
+// workgroup accumulates shader-clock cycles per phase and writes 8 numbers per QP into `trace`.
+#ifdef QPX_PROFILE
+#define QPX_PROF_INIT long long qpx_prof_t = clock64(); long long qpx_prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define QPX_PROF(i) { const long long qpx_prof_n = clock64(); qpx_prof_acc[i] += qpx_prof_n - qpx_prof_t; qpx_prof_t = qpx_prof_n; }
+#define QPX_PROF_DUMP(ptr, T) if (b.tid == 0 && (ptr)) { for (int qpx_i = 0; qpx_i < 8; ++qpx_i) (ptr)[qpx_i] = (T)qpx_prof_acc[qpx_i]; }
+#else
+#define QPX_PROF_INIT
+#define QPX_PROF(i)
+#define QPX_PROF_DUMP(ptr, T)
+#endif
+
 namespace qpx {
 
 template <class T> struct Lim;
@@ -177,7 +189,24 @@ template <class T> QPX_DEV bool chol_packed(const Block& b, T* P, int n, T* dinv
         for (int i = k + 1 + ti; i < n; i += TI) {
             T* Pi = P + tri(i);
             const T lik = Pi[k] * rk;
-            for (int j = k + 1 + tj; j <= i; j += TJ) Pi[j] = fma_(-lik, P[tri(j) + k], Pi[j]);
+            // four independent read-modify-writes in flight per pass (the LDS latency, not the
+            // FMA rate, bounds this loop)
+            for (int j0 = k + 1 + tj; j0 <= i; j0 += 4 * TJ) {
+                T pij[4], pjk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * TJ;
+                    if (j <= i) {
+                        pij[u] = Pi[j];
+                        pjk[u] = P[tri(j) + k];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * TJ;
+                    if (j <= i) Pi[j] = fma_(-lik, pjk[u], pij[u]);
+                }
+            }
         }
     }
     b.sync();
@@ -330,6 +359,9 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
         Lq = F + lay.L; Z = F + lay.Zp; Yh = F + lay.Yh; V = F + lay.V; L11 = F + lay.L11;
     }
 
+    // register-layout copy of R for the wave-per-QP kernel: zero it first (padding, upper parts)
+    if (lay.nbw > 0)
+        for (size_t e = b.tid; e < (size_t)(lay.nbw * (lay.nbw + 1) / 2) * 64; e += b.nt) F[lay.Rw + e] = T(0);
     // A. symmetrised lower triangle of Q -> packed
     for (int idx = b.tid; idx < n * n; idx += b.nt) {
         const int i = idx / n, j = idx - i * n;
@@ -443,7 +475,15 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int i = 4 * ti + r, j = 4 * tj + c;
-                    if (i < m && j <= i) Rg[tri(i) + j] = acc[r][c];
+                    if (i < m && j <= i) {
+                        Rg[tri(i) + j] = acc[r][c];
+                        if (lay.nbw > 0) {
+                            const int li = i >> 3, ai = i & 7, lj = j >> 3, bj = j & 7;
+                            T* blk = F + lay.Rw + (size_t)(li * (li + 1) / 2 + lj) * 64;
+                            blk[ai + 8 * bj] = acc[r][c];
+                            if (li == lj && i != j) blk[bj + 8 * ai] = acc[r][c];   // diagonal blocks are held in full
+                        }
+                    }
                 }
         }
     }
@@ -566,6 +606,7 @@ QPX_DEV void ipm_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
 #pragma unroll
     for (int k = 0; k < NS; ++k) { z[k] = s[k] = bz[k] = bs[k] = T(1); c[k] = r1[k] = rzp[k] = T(0); }
 
+    QPX_PROF_INIT
     // ---- constants that depend on p, h, b (they enter the reference through the start-point
     //      solve, batch.py:64-67):  t = L^-1 p, beta = L11^-1 b,
     //      w0 = -(t - Yh Yh^T t) + Yh beta,  c = h + Zp^T t - V^T beta,  ycoef = beta + Yh^T t
@@ -616,6 +657,7 @@ QPX_DEV void ipm_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         for (int r = b.tid; r < q; r += b.nt) vQ1[r] += vQ2[r];
     }
 
+    QPX_PROF(0)
     // ---- start point: d = 1 (batch.py:61-67): z_i = -(R + I)^-1 c, s_i = -z_i, then shifts
     block_copy(b, Tm, Rg, tri(m));
     b.sync();
@@ -667,13 +709,16 @@ QPX_DEV void ipm_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     }
     b.sync();
     int stop = ctrl[0];
+    QPX_PROF(1)
 
     for (int it = 0; it < a.maxIter && !stop; ++it) {
         // T <- R ; R z'
         block_copy(b, Tm, Rg, tri(m));
         b.sync();
+        QPX_PROF(2)
         block_symv_packed(b, Tm, m, vA, vB);
         b.sync();
+        QPX_PROF(3)
         T mu = 0, feas = 0, resid = 0, szdot = 0;
         if (w0) {
             ld_slots<NS>(b, rzp, vB, m, T(0));
@@ -701,7 +746,10 @@ QPX_DEV void ipm_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
                 tr[0] = pri; tr[1] = dual; tr[2] = mu;
             }
         }
+        b.sync();
+        QPX_PROF(4)
         ok = chol_packed(b, Tm, m, dinv);                            // factor_kkt  batch.py:110
+        QPX_PROF(5)
         if (w0) {
             int stopf = 0;
             if (!ok) {
@@ -789,6 +837,7 @@ QPX_DEV void ipm_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         }
         b.sync();
         stop = ctrl[0];
+        QPX_PROF(6)
     }
 
     // ---- outputs: best iterate (batch.py:143,207): lam = z, slacks = s, zhat = x, nu = y
@@ -860,6 +909,8 @@ QPX_DEV void ipm_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
             st_slots<NS>(b, a.nu + (size_t)qp * q, y, q);
         }
     }
+    QPX_PROF(7)
+    QPX_PROF_DUMP(a.trace ? a.trace + (size_t)qp * 8 : (T*)nullptr, T)
 }
 
 // ------------------------------------------------------------------------------------------

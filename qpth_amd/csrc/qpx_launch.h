@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "qpx_kernels.h"
+#include "qpx_wave.h"
 
 namespace qpx {
 
@@ -22,5 +23,8 @@ template <class T, int NS, bool kLds>
 int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
 template <class T, int NS, bool kLds, bool kBw>
 int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream);
+// wave-per-QP PDIPM loop (qpx_wave.h): workgroup = one wave64
+template <class T, int NB, int NS>
+int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
 
 }  // namespace qpx

@@ -17,6 +17,9 @@
 //   r1     m          R 1
 //   scal   4          [0] = || G^T 1 ||_2
 //   T      m(m+1)/2   scratch: Cholesky factor of R + diag(1/d) when it does not fit in LDS
+//   Rw     64*nb(nb+1)/2  R again, in the REGISTER LAYOUT of the wave-per-QP kernel (qpx_wave.h):
+//                     entry [(li(li+1)/2 + lj)*64 + a + 8b] = R[8li+a][8lj+b], li >= lj, zero padded to
+//                     8*nb x 8*nb; nb = wave_nb(m); absent (nb = 0) when m is too large for that kernel
 #pragma once
 #include <cstddef>
 
@@ -29,10 +32,25 @@ namespace qpx {
 #endif
 
 QPX_LAYOUT_HD size_t tri(size_t i) { return i * (i + 1) / 2; }
+QPX_LAYOUT_HD int tri(int i) { return i * (i + 1) / 2; }   // 32-bit form for kernel index math
 QPX_LAYOUT_HD size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
 
+// Number of 8-row blocks the wave-per-QP kernel is instantiated with for nineq = m (0: not
+// available, the workgroup kernel runs instead).  One list for both dtypes so that the blob
+// layout does not depend on dtype.
+QPX_LAYOUT_HD int wave_nb(int m)
+{
+    const int need = (m + 7) / 8;
+    if (need <= 2) return 2;
+    if (need <= 4) return 4;
+    if (need <= 8) return 8;
+    if (need <= 13) return 13;
+    return 0;
+}
+
 struct FacLayout {
-    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, total;
+    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, Rw, total;
+    int nbw;
 };
 
 QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
@@ -50,6 +68,8 @@ QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
     f.r1 = o;     o += align4(m);
     f.scal = o;   o += 4;
     f.T = o;      o += align4(tri(m));
+    f.nbw = wave_nb(m);
+    f.Rw = o;     o += (size_t)(f.nbw * (f.nbw + 1) / 2) * 64;
     f.total = o;
     return f;
 }

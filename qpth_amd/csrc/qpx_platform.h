@@ -25,8 +25,17 @@ struct Block {
     QPX_DEV int wave() const { return tid >> 6; }
     QPX_DEV int nwaves() const { return nt >> 6; }
 
-    // workgroup barrier; LDS and global writes of the workgroup made before it are visible after
-    QPX_DEV void sync() const { __syncthreads(); }
+    // workgroup barrier; LDS and global writes of the workgroup made before it are visible after.
+    // The explicit wait is load-bearing: hipcc (ROCm 7.2) dropped the `s_waitcnt lgkmcnt(0)`
+    // that belongs to __syncthreads() on the back-edge of the Cholesky column loop (every other
+    // barrier of the kernel kept it), so a ds_write of one wave could still be in flight when
+    // another wave read the element after the barrier -- seen on MI355X as ~1 QP in 4096
+    // spuriously flagged "not SPD".  Inline asm is invisible to the pass that removes the wait.
+    QPX_DEV void sync() const
+    {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     // ordering point for LDS traffic between lanes of ONE wave.  A wave's DS instructions
     // execute in issue order, so only the compiler must be kept from moving them.
@@ -55,6 +64,35 @@ struct Block {
     }
     QPX_DEV int bcast(int v, int src) const { return __builtin_amdgcn_readlane(v, src); }
 };
+
+// Rows of 64 consecutive elements of a wave-uniform global array, read as one coalesced
+// 64-lane load each: row(r) = base[r*64 + lane].  Implemented with buffer loads (SGPR resource
+// + SGPR row offset + one VGPR lane offset) so that a kernel which reads ~100 different rows in
+// a loop does not keep ~100 64-bit VGPR addresses alive (measured: global_load with per-row
+// VGPR pairs cost 160+ VGPRs at NB = 13).
+template <class T> struct GlobalRows {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;
+    QPX_DEV GlobalRows(const T* base, int nelem, int lane)
+    {
+        // readfirstlane: make the descriptor provably wave-uniform (no waterfall loop per load)
+        const unsigned long long p = (unsigned long long)base;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(p & 0xffffffffull));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        void* up = (void*)(((unsigned long long)hi << 32) | lo);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(up, 0, nelem * (int)sizeof(T), 0x00020000);
+        voff = lane * (int)sizeof(T);
+    }
+    QPX_DEV T row(int r) const;
+};
+template <> QPX_DEV float GlobalRows<float>::row(int r) const
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, r * kWave * 4, 0));
+}
+template <> QPX_DEV double GlobalRows<double>::row(int r) const
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, r * kWave * 8, 0));
+}
 
 template <class T> QPX_DEV T fma_(T a, T b, T c);
 template <> QPX_DEV float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

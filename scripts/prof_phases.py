@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Phase breakdown of k_ipm from the profiling build (libqpx_hip_prof.so, -DQPX_PROFILE):
+shader-clock cycles thread 0 of each workgroup spent per phase, averaged over the batch."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import problems  # noqa: E402
+from qpth_amd import _lib  # noqa: E402
+from qpth_amd.kkt import KKTFactors  # noqa: E402
+
+NAMES = ["consts(p,h,b)", "start point", "copy R->T", "symv R z'", "residuals(w0)", "cholesky", "newton(w0)", "epilogue"]
+
+
+def main():
+    B, n, m, q = [int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (512, 100, 100, 0))]
+    dt = np.float32 if (len(sys.argv) > 5 and sys.argv[5] == "f32") else np.float64
+    dev = torch.device("cuda:0")
+    lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_prof.so"))
+    _lib.set_test_backend(lib)        # explicit: route this script's calls to the profiling build
+    arrs = problems.prof_qp(B, n, m, q, 0, dt)
+    tQ, tp, tG, th, tA, tb = [torch.tensor(x, device=dev) for x in arrs]
+    fac = KKTFactors.build(tQ, tG, tA, B)
+    for rep in range(3):
+        res = fac.ipm(tp, th, tb, want_trace=True)
+        torch.cuda.synchronize()
+    cyc = res.trace.reshape(-1)[:B * 8].reshape(B, 8).double().cpu().numpy()
+    iters = res.iters.cpu().numpy()
+    tot = cyc.sum(1)
+    print("B=%d n=%d m=%d q=%d %s  iterations mean %.2f  total cycles/QP mean %.0f max %.0f" % (
+        B, n, m, q, dt.__name__, iters.mean(), tot.mean(), tot.max()))
+    for i, nm in enumerate(NAMES):
+        per_it = cyc[:, i].mean() / iters.mean() if 2 <= i <= 6 else float("nan")
+        print("  %-16s %12.0f cycles (%5.1f%%)   per iteration %10.0f" % (nm, cyc[:, i].mean(), 100 * cyc[:, i].sum() / tot.sum(), per_it))
+
+
+if __name__ == "__main__":
+    main()

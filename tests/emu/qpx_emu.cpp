@@ -13,6 +13,7 @@
 #include "../../include/qpx.h"
 #include "qpx_platform.h"  // the emulation header: defines QPX_PLATFORM_H, so the HIP one is skipped
 #include "qpx_kernels.h"
+#include "qpx_wave.h"
 
 namespace qpx {
 
@@ -106,6 +107,17 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void*)
         std::vector<unsigned char> lds(lds_bytes + 64);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(nt, [&](const Block& b) { kkt_body<T, NS, kLds, kBw>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
+
+template <class T, int NB, int NS>
+int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + 64);
+        T* base = reinterpret_cast<T*>(lds.data());
+        run_block(kWave, [&](const Block& b) { ipm_wave_body<T, NB, NS>(b, a, qp, base); });
     }
     return QPX_OK;
 }

@@ -59,6 +59,13 @@ struct Block {
     int bcast(int v, int src) const { return exchange(v, src); }
 };
 
+template <class T> struct GlobalRows {
+    const T* base;
+    int lane;
+    GlobalRows(const T* b, int /*nelem*/, int l) : base(b), lane(l) {}
+    T row(int r) const { return base[(size_t)r * kWave + lane]; }
+};
+
 template <class T> inline T fma_(T a, T b, T c) { return std::fma(a, b, c); }
 inline float sqrt_(float x) { return std::sqrt(x); }
 inline double sqrt_(double x) { return std::sqrt(x); }
