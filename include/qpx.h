@@ -81,9 +81,13 @@ size_t qpx_factor_elems(int n, int m, int q);
 int qpx_max_dim(void);
 int qpx_fits_lds(int dtype, int n, int m, int q);
 
-/* tuning/A-B knob: which PDIPM kernel qpx_ipm launches.  0 (default) = automatic: one wave64
- * per QP with the m x m matrix in registers when nineq <= 104 and nz <= 128, else one
- * 256-thread workgroup per QP; 1 = always the workgroup kernel.  Returns the previous value. */
+/* tuning/A-B knob: which kernel family runs.  0 (default) = automatic: the 16x16 thread-grid
+ * kernels (sweep pre-factorisation, register-resident LDL^T with in-place inverse factor)
+ * whenever nz+neq+nineq <= 208, else one 256-thread workgroup per QP with the matrices in LDS
+ * (or in HBM when they do not fit); 1 = always the workgroup kernels; 2 = workgroup
+ * pre-factorisation/backward + the one-wave-per-QP loop (nineq <= 104, nz <= 128).
+ * The knob must not change between qpx_pre_factor and the calls that consume its factors.
+ * Returns the previous value. */
 int qpx_set_ipm_variant(int variant);
 
 /* pre_factor_kkt(Q, G, A) */

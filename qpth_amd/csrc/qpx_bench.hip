@@ -1,0 +1,199 @@
+// qpx_bench.hip -- micro-benchmarks of the gfx950 primitives the wave-per-QP kernel is built from
+// (NOT part of libqpx_hip.so; built as libqpx_bench.so by `make bench`, driven by scripts/ubench.py).
+// Every kernel runs single-wave workgroups and reports shader-clock cycles (clock64) per
+// operation for wave 0 of every block.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "qpx_wave.h"
+
+using namespace qpx;
+
+#define BENCH_KERNEL(name) __global__ __launch_bounds__(64) void name(double* out, const double* in, int reps)
+
+// 1. independent f64 FMAs: issue rate
+BENCH_KERNEL(k_fma_tput)
+{
+    double a0 = in[threadIdx.x], a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const double m = in[64], c = in[65];
+    long long w0 = wall_clock64();
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 = __builtin_fma(a0, m, c); a1 = __builtin_fma(a1, m, c); a2 = __builtin_fma(a2, m, c); a3 = __builtin_fma(a3, m, c);
+            a4 = __builtin_fma(a4, m, c); a5 = __builtin_fma(a5, m, c); a6 = __builtin_fma(a6, m, c); a7 = __builtin_fma(a7, m, c);
+        }
+    }
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    long long w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[4096 + blockIdx.x] = double(t1 - t0) / (64.0 * reps);
+        out[8192 + blockIdx.x] = double(w1 - w0) / (64.0 * reps);     // 100 MHz ticks per instruction
+        out[12288 + blockIdx.x] = double(t1 - t0) / double(w1 - w0);  // clock64 ticks per 10 ns
+    }
+}
+// 2. dependent f64 FMA chain: latency
+BENCH_KERNEL(k_fma_lat)
+{
+    double a0 = in[threadIdx.x];
+    const double m = in[64], c = in[65];
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) a0 = __builtin_fma(a0, m, c);
+    }
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = a0;
+    if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (64.0 * reps);
+}
+// 3. dependent LDS read chain (pointer chasing): ds_read latency
+BENCH_KERNEL(k_lds_lat)
+{
+    __shared__ int next[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) next[i] = (i * 37 + 11) & 1023;
+    __syncthreads();
+    int p = threadIdx.x;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) p = next[p];
+    }
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = p;
+    if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (32.0 * reps);
+}
+// 4. LDS write by one lane group -> read by all lanes, dependent: publish/consume round trip
+BENCH_KERNEL(k_lds_roundtrip)
+{
+    __shared__ double buf[256];
+    const Block b{(int)threadIdx.x, 64};
+    double v = in[threadIdx.x];
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if ((threadIdx.x >> 3) == (u & 7)) buf[(threadIdx.x & 7) + 8 * u] = v;
+            b.wave_sync();
+            v = v * 0.5 + buf[(threadIdx.x >> 3) + 8 * u];
+        }
+    }
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = v;
+    if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (16.0 * reps);
+}
+// 5. readlane -> fma chain (the substitution step)
+BENCH_KERNEL(k_readlane_chain)
+{
+    const Block b{(int)threadIdx.x, 64};
+    double x = in[threadIdx.x];
+    const double l = in[64 + threadIdx.x] * 1e-3;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+        for (int k = 0; k < 64; ++k) {
+            const double yk = b.bcast(x, k);
+            x = __builtin_fma(-l, yk, x);
+        }
+    }
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = x;
+    if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (64.0 * reps);
+}
+// 6. reciprocal: rcp_ (estimate + 2 Newton) and full division, dependent chains
+BENCH_KERNEL(k_rcp_lat)
+{
+    double x = in[threadIdx.x] + 1.5, y = x;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x = rcp_(x) + 1.25;
+    }
+    long long t1 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) y = 1.0 / y + 1.25;
+    }
+    long long t2 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = x + y;
+    if (threadIdx.x == 0) {
+        out[4096 + blockIdx.x] = double(t1 - t0) / (16.0 * reps);
+        out[8192 + blockIdx.x] = double(t2 - t1) / (16.0 * reps);
+    }
+}
+// 7. ds_bpermute (shfl_xor) dependent chain and 8-wide independent
+BENCH_KERNEL(k_bpermute)
+{
+    const Block b{(int)threadIdx.x, 64};
+    double x = in[threadIdx.x];
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) x += b.shfl_xor(x, 1 << u);
+    }
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = x;
+    if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (6.0 * reps);
+}
+
+// 8. the real routines: register-resident LDL^T and the two substitutions, NB = 13 / 8
+template <int NB, int MODE> __global__ __launch_bounds__(64) void k_ldl(double* out, const double* Rw, int reps, int m)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* Lc = reinterpret_cast<double*>(smem);
+    double* rd = Lc + (8 * NB) * (8 * NB + 1) / 2 + 8;
+    const Block b{(int)threadIdx.x, 64};
+    const double* mine = Rw + (size_t)blockIdx.x * wave_tri(NB) * 64;
+    double Tr[wave_tri(NB)];
+    long long tl = 0, tf = 0, ts = 0;
+    bool ok = true;
+    double acc = 0;
+    for (int r = 0; r < reps; ++r) {
+        wave_load_R<double, NB>(b, Tr, mine);
+        long long t0 = clock64();
+        ok = wave_ldl<double, NB>(b, Tr, Lc, rd, m) && ok;
+        long long t1 = clock64();
+        double x[2] = {1.0 + threadIdx.x, 2.0};
+        if (MODE >= 1) wtrsv_fwd<2>(b, Lc, rd, 8 * NB, m, x);
+        long long t2 = clock64();
+        if (MODE >= 1) wtrsv_bwd<2>(b, Lc, rd, 8 * NB, m, x);
+        long long t3 = clock64();
+        tl += t1 - t0; tf += t2 - t1; ts += t3 - t2;
+        acc += x[0] + x[1];
+    }
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = acc + (ok ? 0.0 : 1e300);
+    if (threadIdx.x == 0) {
+        out[4096 + blockIdx.x] = double(tl) / reps;
+        out[8192 + blockIdx.x] = double(tf) / reps;
+        out[12288 + blockIdx.x] = double(ts) / reps;
+    }
+}
+
+extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, const double* in, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    switch (which) {
+    case 1: hipLaunchKernelGGL(k_fma_tput, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 2: hipLaunchKernelGGL(k_fma_lat, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 3: hipLaunchKernelGGL(k_lds_lat, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 4: hipLaunchKernelGGL(k_lds_roundtrip, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 5: hipLaunchKernelGGL(k_readlane_chain, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 6: hipLaunchKernelGGL(k_rcp_lat, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 7: hipLaunchKernelGGL(k_bpermute, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 13: {
+        auto k = k_ldl<13, 1>;
+        const size_t lds = ((104 * 105) / 2 + 8 + 104 + 8) * 8;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(64), lds, s, out, in, reps, m);
+        break;
+    }
+    case 8: {
+        auto k = k_ldl<8, 1>;
+        const size_t lds = ((64 * 65) / 2 + 8 + 64 + 8) * 8;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(64), lds, s, out, in, reps, m);
+        break;
+    }
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

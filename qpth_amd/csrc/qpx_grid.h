@@ -1,0 +1,875 @@
+// qpx_grid.h -- the "thread-grid" kernels: a GS x GS grid of threads (GS = 16: one 256-thread
+// workgroup; GS = 8: one wave64) owns one QP and keeps its symmetric work matrix REGISTER-RESIDENT
+// in a 2-D cyclic layout: thread (a, b) = (tid % GS, tid / GS) holds the elements
+// (GS*li + a, GS*lj + b), li >= lj, of the lower block triangle as NBL(NBL+1)/2 registers
+// (diagonal GS x GS blocks are held in full).
+//
+// The design follows what the MI355X micro-benchmarks (scripts/ubench.py, profiles/) say:
+// dependent f64 FMAs issue back to back (4.7 ticks), an LDS publish->consume round trip is ~85
+// ticks, rcp ~42 -- but a triangular substitution step costs a serial readlane->fma chain per
+// column, and four of them per IPM iteration cost more than the factorisation itself.  So the
+// factorisation here produces the INVERSE of the unit-lower factor in place:
+//
+//   ldl_inv:  T = L~ D L~^T by right-looking rank-1 updates; the registers of the columns that
+//             have been eliminated are reused for W~ = L~^-1, which is built by the SAME rank-1
+//             update (row i > k of W~ gets -l~_ik * row k of W~).  One published vector and one
+//             barrier per column; no substitutions afterwards:
+//   solve:    x = -T^-1 r = -W~^T D^-1 W~ r  -- two triangular mat-vecs, all threads busy.
+//
+// Accuracy: the explicit unit-lower inverse loses nothing measurable against substitution on the
+// IPM's matrices (z* error vs the reference 2.7e-12 max at C2 in f64; a full explicit T^-1 by
+// Gauss-Jordan would lose 7 digits) -- see DESIGN.md section 7.
+#pragma once
+#include "qpx_kernels.h"
+
+namespace qpx {
+
+constexpr int gtri(int x) { return x * (x + 1) / 2; }
+constexpr int gidx(int li, int lj) { return li * (li + 1) / 2 + lj; }   // li >= lj
+
+template <int GS> struct GridPos {
+    int tid, a, b;
+    static constexpr int NT = GS * GS;
+    QPX_DEV explicit GridPos(const Block& blk) : tid(blk.tid), a(blk.tid % GS), b(blk.tid / GS) {}
+    // all threads of the grid reach this point; LDS writes before it are visible after it
+    static QPX_DEV void sync(const Block& blk)
+    {
+        if (GS == 8) blk.wave_sync();
+        else blk.sync();
+    }
+};
+
+// element count of the grid-layout copy of a symmetric matrix of NBL x NBL blocks
+QPX_LAYOUT_HD size_t grid_elems(int gs, int nbl) { return (size_t)(nbl * (nbl + 1) / 2) * gs * gs; }
+
+// E <- matrix stored in grid layout: entry [gidx(li,lj)*GS*GS + tid]
+template <class T, int GS, int NBL>
+QPX_DEV void grid_load(const Block& blk, T (&E)[gtri(NBL)], const T* Rg)
+{
+    constexpr int NT = GS * GS;
+    if (GS == 8) {
+        const GlobalRows<T> rows(Rg, gtri(NBL) * NT, blk.tid);
+#pragma unroll
+        for (int e = 0; e < gtri(NBL); ++e) E[e] = rows.row(e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < gtri(NBL); ++e) E[e] = Rg[(size_t)e * NT + blk.tid];
+    }
+}
+
+// Sum NBL per-thread partials over one grid axis through LDS and (accumulate) into out[GS*l + r].
+// kOverB: sum over b (result indexed by a: "row sums"), else over a ("column sums").
+template <class T, int GS, int NBL, bool kOverB, bool kAccumulate>
+QPX_DEV void grid_reduce(const Block& blk, const GridPos<GS>& g, const T (&part)[NBL], T* red, T* out)
+{
+    constexpr int NT = GS * GS;
+    const int r = kOverB ? g.a : g.b, c = kOverB ? g.b : g.a;
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) red[(l * GS + r) * GS + c] = part[l];
+    GridPos<GS>::sync(blk);
+    for (int idx = g.tid; idx < NBL * GS; idx += NT) {
+        const T* p = red + idx * GS;
+        T s = T(0);
+#pragma unroll
+        for (int k = 0; k < GS; ++k) s += p[k];
+        out[idx] = kAccumulate ? (out[idx] + s) : s;
+    }
+    GridPos<GS>::sync(blk);
+}
+
+// vout = S vin for the symmetric matrix in E (lower blocks, diagonal blocks in full).
+template <class T, int GS, int NBL>
+QPX_DEV void grid_symv(const Block& blk, const GridPos<GS>& g, const T (&E)[gtri(NBL)], const T* vin, T* vout, T* red)
+{
+    T racc[NBL], cacc[NBL];
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) racc[l] = cacc[l] = T(0);
+#pragma unroll
+    for (int li = 0; li < NBL; ++li) {
+        const T vri = vin[GS * li + g.a];
+#pragma unroll
+        for (int lj = 0; lj <= li; ++lj) {
+            const T t = E[gidx(li, lj)];
+            racc[li] = fma_(t, vin[GS * lj + g.b], racc[li]);
+            if (li != lj) cacc[lj] = fma_(t, vri, cacc[lj]);
+        }
+    }
+    grid_reduce<T, GS, NBL, true, false>(blk, g, racc, red, vout);
+    grid_reduce<T, GS, NBL, false, true>(blk, g, cacc, red, vout);
+}
+
+template <class T, int GS, int NBL>
+QPX_DEV void grid_add_diag(const GridPos<GS>& g, T (&E)[gtri(NBL)], const T* vd)
+{
+    if (g.a == g.b) {
+#pragma unroll
+        for (int l = 0; l < NBL; ++l) E[gidx(l, l)] += vd[GS * l + g.a];
+    }
+}
+
+// One column step of ldl_inv for column k = GS*KB + ka.  `vec` (double buffered by the parity of
+// k) receives: rows i > k: c_ik (un-scaled column k of the Schur complement), cols j < k:
+// W~_kj (row k of the inverse factor, final), entry k: d_k + 1; `dsl[parity]` the pivot d_k.
+template <class T, int GS, int NBL, int KB>
+QPX_DEV bool grid_ldl_inv_step(const Block& blk, const GridPos<GS>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, T* rd, int ka)
+{
+    constexpr int M = GS * NBL;
+    const int k = GS * KB + ka;
+    T* vec = vec2 + (k & 1) * M;
+    // ---- publish
+    if (g.b == ka) {
+#pragma unroll
+        for (int li = KB; li < NBL; ++li) {
+            const int i = GS * li + g.a;
+            if (i > k) vec[i] = E[gidx(li, KB)];
+        }
+    }
+    if (g.a == ka) {
+#pragma unroll
+        for (int lj = 0; lj <= KB; ++lj) {
+            const int j = GS * lj + g.b;
+            if (j < k) vec[j] = E[gidx(KB, lj)];
+        }
+        if (g.b == ka) {
+            const T d = E[gidx(KB, KB)];
+            vec[k] = d + T(1);
+            dsl[k & 1] = d;
+        }
+    }
+    GridPos<GS>::sync(blk);
+    // ---- consume
+    const T dk = dsl[k & 1];
+    if (!(dk > T(0)) || !finite_(dk)) return false;
+    const T r = rcp_(dk);
+    if (g.tid == 0) rd[k] = r;
+    T lrow[NBL];
+#pragma unroll
+    for (int li = KB; li < NBL; ++li) {
+        const T v = vec[GS * li + g.a];
+        lrow[li] = (li > KB || g.a > ka) ? v * r : T(0);      // rows <= k take no part
+    }
+#pragma unroll
+    for (int lj = 0; lj < NBL; ++lj) {
+        const T y = vec[GS * lj + g.b];
+#pragma unroll
+        for (int li = (lj > KB ? lj : KB); li < NBL; ++li) E[gidx(li, lj)] = fma_(-lrow[li], y, E[gidx(li, lj)]);
+    }
+    return true;
+}
+
+template <class T, int GS, int NBL, int KB> struct GridLdlBlocks {
+    static QPX_DEV bool run(const Block& blk, const GridPos<GS>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, T* rd, int m)
+    {
+        if (GS * KB >= m) return true;               // the pad is the identity: nothing to eliminate
+        const int kend = (m - GS * KB < GS) ? (m - GS * KB) : GS;
+#pragma unroll 1
+        for (int ka = 0; ka < kend; ++ka)
+            if (!grid_ldl_inv_step<T, GS, NBL, KB>(blk, g, E, vec2, dsl, rd, ka)) return false;
+        return GridLdlBlocks<T, GS, NBL, KB + 1>::run(blk, g, E, vec2, dsl, rd, m);
+    }
+};
+template <class T, int GS, int NBL> struct GridLdlBlocks<T, GS, NBL, NBL> {
+    static QPX_DEV bool run(const Block&, const GridPos<GS>&, T (&)[gtri(NBL)], T*, T*, T*, int) { return true; }
+};
+
+// E: T (SPD, order m padded with the identity) -> strictly-lower part: W~ = L~^-1, diagonal: d_k.
+// rd[k] = 1/d_k.  vec2: 2*GS*NBL elements of LDS, dsl: 2.  Uniform return value.
+template <class T, int GS, int NBL>
+QPX_DEV bool grid_ldl_inv(const Block& blk, const GridPos<GS>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, T* rd, int m)
+{
+    const bool ok = GridLdlBlocks<T, GS, NBL, 0>::run(blk, g, E, vec2, dsl, rd, m);
+    GridPos<GS>::sync(blk);
+    return ok;
+}
+
+// vout = -T^-1 vin = -W~^T D^-1 W~ vin with W~ (unit lower) in E; vin, vout, tmp: LDS vectors of
+// length GS*NBL (pad entries of vin must be zero); entries >= m of rd are not read.
+template <class T, int GS, int NBL>
+QPX_DEV void grid_solve_neg(const Block& blk, const GridPos<GS>& g, const T (&E)[gtri(NBL)], const T* rd, int m,
+                            const T* vin, T* vout, T* tmp, T* red)
+{
+    constexpr int NT = GS * GS;
+    T acc[NBL];
+    // y = W~ vin   (row sums over j < i, plus the unit diagonal)
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) acc[l] = T(0);
+#pragma unroll
+    for (int li = 0; li < NBL; ++li)
+#pragma unroll
+        for (int lj = 0; lj <= li; ++lj) {
+            const T w = (lj < li || g.b < g.a) ? E[gidx(li, lj)] : T(0);
+            acc[li] = fma_(w, vin[GS * lj + g.b], acc[li]);
+        }
+    grid_reduce<T, GS, NBL, true, false>(blk, g, acc, red, tmp);
+    for (int i = g.tid; i < GS * NBL; i += NT) tmp[i] = (i < m) ? (tmp[i] + vin[i]) * rd[i] : T(0);   // u = D^-1 y
+    GridPos<GS>::sync(blk);
+    // x = W~^T u   (column sums over i > j, plus the unit diagonal)
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) acc[l] = T(0);
+#pragma unroll
+    for (int li = 0; li < NBL; ++li) {
+        const T ui = tmp[GS * li + g.a];
+#pragma unroll
+        for (int lj = 0; lj <= li; ++lj) {
+            const T w = (lj < li || g.b < g.a) ? E[gidx(li, lj)] : T(0);
+            acc[lj] = fma_(w, ui, acc[lj]);
+        }
+    }
+    grid_reduce<T, GS, NBL, false, false>(blk, g, acc, red, vout);
+    for (int i = g.tid; i < GS * NBL; i += NT) vout[i] = -(vout[i] + tmp[i]);
+    GridPos<GS>::sync(blk);
+}
+
+QPX_LAYOUT_HD size_t lds_elems_ipm_grid(int gs, int nbl, int n, int q)
+{
+    const size_t mg = (size_t)gs * nbl;
+    const size_t v = align4(max2(max2((size_t)n, mg), (size_t)q));
+    return 12 * v + 2 * mg + 8 + (size_t)nbl * gs * gs;
+}
+
+// out[c] (op)= sum_r Mat[r][c] * vec[r]   -- thread per column c: the loads of a row are
+// coalesced across threads and independent across r (deep memory pipeline, no reduction).
+template <class T, int MODE /*0: =, 1: +=, 2: -=*/>
+QPX_DEV void block_matTvec(const Block& blk, T* out, const T* Mat, const T* vec, int rows, int cols)
+{
+    for (int c = blk.tid; c < cols; c += blk.nt) {
+        T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int r = 0;
+        for (; r + 4 <= rows; r += 4) {
+            a0 = fma_(Mat[(size_t)r * cols + c], vec[r], a0);
+            a1 = fma_(Mat[(size_t)(r + 1) * cols + c], vec[r + 1], a1);
+            a2 = fma_(Mat[(size_t)(r + 2) * cols + c], vec[r + 2], a2);
+            a3 = fma_(Mat[(size_t)(r + 3) * cols + c], vec[r + 3], a3);
+        }
+        for (; r < rows; ++r) a0 = fma_(Mat[(size_t)r * cols + c], vec[r], a0);
+        const T sum = (a0 + a1) + (a2 + a3);
+        out[c] = MODE == 0 ? sum : (MODE == 1 ? out[c] + sum : out[c] - sum);
+    }
+}
+
+// One pivot of the symmetric sweep operator on the register-resident matrix (pivot k = 16*KB + ka):
+//   E_ij -= v_i v_j / d for all i, j  with v = column k (v_k := d - 1, which makes the same
+//   formula produce E_ik = v_i / d),  then E_kk = -1/d.
+// Pivots k < npos must be positive (SPD Q), the others negative (-A Q^-1 A^T).
+template <class T, int NBL, int KB>
+QPX_DEV int sweep_step(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, int ka, int npos)
+{
+    constexpr int GS = 16, MA = GS * NBL;
+    const int k = GS * KB + ka;
+    T* vec = vec2 + (k & 1) * MA;
+    if (g.b == ka) {
+#pragma unroll
+        for (int li = KB; li < NBL; ++li) {
+            const int i = GS * li + g.a;
+            if (i > k) vec[i] = E[gidx(li, KB)];
+        }
+    }
+    if (g.a == ka) {
+#pragma unroll
+        for (int lj = 0; lj <= KB; ++lj) {
+            const int j = GS * lj + g.b;
+            if (j < k) vec[j] = E[gidx(KB, lj)];
+        }
+        if (g.b == ka) {
+            const T d = E[gidx(KB, KB)];
+            vec[k] = d - T(1);
+            dsl[k & 1] = d;
+        }
+    }
+    GridPos<GS>::sync(blk);
+    const T d = dsl[k & 1];
+    const bool okp = (k < npos) ? (d > T(0)) : (d < T(0));
+    if (!okp || !finite_(d)) return (k < npos) ? QPX_ST_Q_NOT_SPD : QPX_ST_A_RANK;
+    const T r = rcp_(d);
+    T vr[NBL];
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) vr[l] = vec[GS * l + g.a] * r;
+#pragma unroll
+    for (int lj = 0; lj < NBL; ++lj) {
+        const T y = vec[GS * lj + g.b];
+#pragma unroll
+        for (int li = lj; li < NBL; ++li) E[gidx(li, lj)] = fma_(-vr[li], y, E[gidx(li, lj)]);
+    }
+    if (g.a == ka && g.b == ka) E[gidx(KB, KB)] = -r;
+    return 0;
+}
+
+template <class T, int NBL, int KB> struct SweepBlocks {
+    static QPX_DEV int run(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, int npos, int npiv)
+    {
+        if (16 * KB >= npiv) return 0;
+        const int kend = (npiv - 16 * KB < 16) ? (npiv - 16 * KB) : 16;
+#pragma unroll 1
+        for (int ka = 0; ka < kend; ++ka) {
+            const int f = sweep_step<T, NBL, KB>(blk, g, E, vec2, dsl, ka, npos);
+            if (f) return f;
+        }
+        return SweepBlocks<T, NBL, KB + 1>::run(blk, g, E, vec2, dsl, npos, npiv);
+    }
+};
+template <class T, int NBL> struct SweepBlocks<T, NBL, NBL> {
+    static QPX_DEV int run(const Block&, const GridPos<16>&, T (&)[gtri(NBL)], T*, T*, int, int) { return 0; }
+};
+
+// ------------------------------------------------------------------------------------------
+// Pre-factorisation by the symmetric SWEEP operator (replaces pre_factor_kkt, batch.py:375-429):
+// the augmented matrix  S = [[Q, A^T, G^T], [A, 0, 0], [G, 0, 0]]  (order n+q+m) is held by a
+// 16x16 thread grid in registers; sweeping the n pivots of Q and then the q pivots of the
+// -A Q^-1 A^T block turns it, in place and by rank-1 updates only, into
+//      [[ -K,   .,     . ],
+//       [ -N^T, S11^-1, . ],
+//       [  M,   W,    -R ]]      K = Q^-1 - Q^-1 A^T S11^-1 A Q^-1,  N = Q^-1 A^T S11^-1,
+//                                M = G K,  W = G N,  R = G K G^T  (the reference's R)
+// i.e. everything forward and backward need, with no triangular solve anywhere.
+template <class T, int NBL>
+QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* lds)
+{
+    constexpr int GS = 16, NT = 256, MA = GS * NBL;
+    const GridPos<GS> g(blk);
+    const int n = a.n, m = a.m, q = a.q, nq = n + q, na = n + q + m;
+    const FacLayout lay = fac_layout(n, m, q);
+    T* F = a.fac + (size_t)qp * a.fac_stride;
+    const T* Qg = a.Q + (size_t)qp * a.sQ;
+    const T* Gg = a.G + (size_t)qp * a.sG;
+    const T* Ag = q > 0 ? a.A + (size_t)qp * a.sA : nullptr;
+    T* vec2 = lds;                 // 2*MA
+    T* dsl = vec2 + 2 * MA;        // 8
+    T* vout = dsl + 8;             // MA
+    T* red = vout + MA;            // NBL*256
+
+    T E[gtri(NBL)];
+    // ---- load the lower triangle of S (diagonal blocks in full)
+#pragma unroll
+    for (int li = 0; li < NBL; ++li)
+#pragma unroll
+        for (int lj = 0; lj <= li; ++lj) {
+            int i = GS * li + g.a, j = GS * lj + g.b;
+            if (j > i) { const int t = i; i = j; j = t; }       // upper part of a diagonal block: mirror
+            T val = T(0);
+            if (i < na && j < n) {
+                if (i < n) val = T(0.5) * (Qg[(size_t)i * n + j] + Qg[(size_t)j * n + i]);
+                else if (i < nq) val = Ag[(size_t)(i - n) * n + j];
+                else val = Gg[(size_t)(i - nq) * n + j];
+            }
+            E[gidx(li, lj)] = val;
+        }
+    // ---- || G^T 1 ||  (column sums of the G block, before it is swept)
+    {
+        T part[NBL];
+#pragma unroll
+        for (int lj = 0; lj < NBL; ++lj) {
+            part[lj] = T(0);
+#pragma unroll
+            for (int li = lj; li < NBL; ++li) {
+                const int i = GS * li + g.a, j = GS * lj + g.b;
+                if (i >= nq && i < na && j < n) part[lj] += E[gidx(li, lj)];
+            }
+        }
+        grid_reduce<T, GS, NBL, false, false>(blk, g, part, red, vout);
+        if (blk.wave() == 0) {
+            T acc = 0;
+            for (int j = blk.lane(); j < n; j += kWave) acc = fma_(vout[j], vout[j], acc);
+            acc = wave_sum(blk, acc);
+            if (blk.lane() == 0) F[lay.scal] = sqrt_(acc);
+        }
+    }
+    // ---- sweep pivots 0 .. n+q-1 (static block index via template recursion, see SweepBlocks)
+    const int fail = SweepBlocks<T, NBL, 0>::run(blk, g, E, vec2, dsl, n, nq);
+    GridPos<GS>::sync(blk);
+    if (fail) {
+        for (size_t e = blk.tid; e < lay.total; e += NT) F[e] = T(0);
+        if (blk.tid == 0) a.status[qp] = fail;
+        return;
+    }
+    // ---- scatter the blocks of the swept matrix to the blob
+    for (size_t e = blk.tid; e < grid_elems(16, lay.nbg); e += NT) F[lay.Rg + e] = T(0);
+    GridPos<GS>::sync(blk);
+#pragma unroll
+    for (int li = 0; li < NBL; ++li)
+#pragma unroll
+        for (int lj = 0; lj <= li; ++lj) {
+            const int i = GS * li + g.a, j = GS * lj + g.b;
+            if (i >= na || j > i) continue;                        // lower triangle only (mirrors are written explicitly)
+            const T val = E[gidx(li, lj)];
+            if (i < n) {                                           // -K (n x n), both triangles
+                F[lay.Kneg + (size_t)i * n + j] = val;
+                F[lay.Kneg + (size_t)j * n + i] = val;
+            } else if (i < nq) {
+                if (j < n) F[lay.NTn + (size_t)(i - n) * n + j] = val;           // -N^T (q x n)
+                else {                                                           // S11^-1 (q x q)
+                    F[lay.S11i + (size_t)(i - n) * q + (j - n)] = val;
+                    F[lay.S11i + (size_t)(j - n) * q + (i - n)] = val;
+                }
+            } else {
+                const int zi = i - nq;
+                if (j < n) {                                                     // M (m x n) and M^T
+                    F[lay.M + (size_t)zi * n + j] = val;
+                    F[lay.MT + (size_t)j * m + zi] = val;
+                } else if (j < nq) {
+                    F[lay.W + (size_t)zi * q + (j - n)] = val;                   // W (m x q)
+                } else {                                                         // R = -block, grid layout of order m
+                    const int zj = j - nq;
+                    const int l2i = zi >> 4, ai = zi & 15, l2j = zj >> 4, bj = zj & 15;
+                    T* blkp = F + lay.Rg + (size_t)(l2i * (l2i + 1) / 2 + l2j) * 256;
+                    blkp[ai + 16 * bj] = -val;
+                    if (l2i == l2j && zi != zj) blkp[bj + 16 * ai] = -val;
+                }
+            }
+        }
+    if (blk.tid == 0) a.status[qp] = 0;
+}
+
+QPX_LAYOUT_HD size_t lds_elems_sweep(int nbl) { return (size_t)3 * 16 * nbl + 8 + (size_t)nbl * 256; }
+
+// ------------------------------------------------------------------------------------------
+// The PDIPM loop on the format-3 blob.  Mathematics and control flow: see ipm_body (same
+// reference citations); the factorisation is ldl_inv and every solve is two triangular mat-vecs.
+template <class T, int GS, int NBL, int NS>
+QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
+{
+    constexpr int M8 = GS * NBL, NT = GS * GS;
+    const GridPos<GS> g(b);
+    const int n = a.n, m = a.m, q = a.q;
+    const FacLayout lay = fac_layout(n, m, q);
+    T* F = a.fac + (size_t)qp * a.fac_stride;
+    const T* Rg = F + lay.Rg;
+    const size_t v = align4(max2(max2((size_t)n, (size_t)M8), (size_t)q));
+    T* rd = lds;          // 1/d_k (M8)
+    T* vA = rd + v;       // z' (M8)
+    T* vB = vA + v;       // R z' (M8)
+    T* vC = vB + v;       // c (M8, zero padded)
+    T* vR1 = vC + v;      // R 1 (M8)
+    T* vD = vR1 + v;      // s/z, 1 on the pad (M8)
+    T* vBZ = vD + v;      // best z
+    T* vBS = vBZ + v;     // best s
+    T* vRH = vBS + v;     // right-hand side of a solve (M8, zero padded)
+    T* vX = vRH + v;      // its solution
+    T* vTm = vX + v;      // scratch of the solve
+    T* vP = vTm + v;      // p / b staging (n)
+    T* vec2 = vP + v;     // 2*M8
+    T* dsl = vec2 + 2 * M8;
+    int* ctrl = reinterpret_cast<int*>(dsl + 4);
+    T* red = dsl + 8;     // NBL*GS*GS
+
+    const int lane = b.lane();
+    const bool w0 = b.wave() == 0;
+    const T mT = (T)m;
+    const T* pg = a.p + (size_t)qp * a.sp;
+    const T* hg = a.h + (size_t)qp * a.sh;
+    const T* bg = q > 0 ? a.b + (size_t)qp * a.sb : nullptr;
+
+    if (a.status[qp] & (QPX_ST_Q_NOT_SPD | QPX_ST_A_RANK)) {
+        const T nanv = Lim<T>::inf() - Lim<T>::inf();
+        for (int i = b.tid; i < n; i += b.nt) a.zhat[(size_t)qp * n + i] = nanv;
+        for (int i = b.tid; i < m; i += b.nt) {
+            a.lam[(size_t)qp * m + i] = nanv;
+            a.slack[(size_t)qp * m + i] = nanv;
+        }
+        for (int i = b.tid; i < q; i += b.nt) a.nu[(size_t)qp * q + i] = nanv;
+        if (b.tid == 0) {
+            a.iters[qp] = 0;
+            a.best_resid[qp] = Lim<T>::inf();
+        }
+        return;
+    }
+    QPX_PROF_INIT
+    // ---- c = h - G x0 = h + M p - W b   (x0 = -K p + N b is formed only at the end)
+    for (int i = b.tid; i < n; i += NT) vP[i] = pg[i];
+    for (int i = b.tid; i < M8; i += NT) {
+        vC[i] = (i < m) ? hg[i] : T(0);
+        vD[i] = T(1);
+        vA[i] = T(1);                     // first use: R 1
+        vRH[i] = T(0);
+    }
+    GridPos<GS>::sync(b);
+    block_matTvec<T, 1>(b, vC, F + lay.MT, vP, n, m);
+    if (q > 0) {
+        GridPos<GS>::sync(b);
+        for (int i = b.tid; i < q; i += NT) vTm[i] = bg[i];
+        GridPos<GS>::sync(b);
+        for (int j = b.tid; j < m; j += NT) {
+            T acc = vC[j];
+            for (int r = 0; r < q; ++r) acc = fma_(-F[lay.W + (size_t)j * q + r], vTm[r], acc);
+            vC[j] = acc;
+        }
+    }
+    GridPos<GS>::sync(b);
+    QPX_PROF(0)
+
+    T E[gtri(NBL)];
+    T z[NS], s[NS];
+    T tau = 1, btau = 1, sigz = 0, sigs = 0, bres = Lim<T>::inf();
+    const T g1n = F[lay.scal];
+    T feas_prev = 0, alpha_prev = 0;
+    int nnot = 0, floor_hit = 0, st = 0, iters = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) z[k] = s[k] = T(1);
+
+    // ---- R 1, then the start point: T = R + I, z_i = -T^-1 c, s_i = -z_i, shifts (batch.py:61-87)
+    grid_load<T, GS, NBL>(b, E, Rg);
+    grid_symv<T, GS, NBL>(b, g, E, vA, vR1, red);
+    grid_add_diag<T, GS, NBL>(g, E, vD);
+    bool ok = grid_ldl_inv<T, GS, NBL>(b, g, E, vec2, dsl, rd, m);
+    if (ok) grid_solve_neg<T, GS, NBL>(b, g, E, rd, m, vC, vX, vTm, red);
+    if (w0) {
+        if (ok) {
+            T x[NS];
+            ld_slots<NS>(b, x, vX, m, T(0));
+            T mnz = Lim<T>::inf(), mns = Lim<T>::inf();
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) {
+                    mnz = (x[k] < mnz) ? x[k] : mnz;
+                    mns = (-x[k] < mns) ? -x[k] : mns;
+                }
+            }
+            mnz = wave_min(b, mnz);
+            mns = wave_min(b, mns);
+            sigz = (mnz < T(0)) ? (T(1) - mnz) : T(0);
+            sigs = (mns < T(0)) ? (T(1) - mns) : T(0);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) {
+                    z[k] = x[k] + sigz;
+                    s[k] = -x[k] + sigs;
+                    vA[i] = x[k];
+                    vBZ[i] = z[k];
+                    vBS[i] = s[k];
+                }
+            }
+        } else {
+            st |= QPX_ST_KKT_BREAKDOWN;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) { vBZ[i] = T(1); vBS[i] = T(1); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            if (i >= m && i < M8) vA[i] = T(0);
+        }
+        if (lane == 0) ctrl[0] = ok ? 0 : 1;
+    }
+    GridPos<GS>::sync(b);
+    int stop = ctrl[0];
+    QPX_PROF(1)
+
+    for (int it = 0; it < a.maxIter && !stop; ++it) {
+        grid_load<T, GS, NBL>(b, E, Rg);
+        QPX_PROF(2)
+        grid_symv<T, GS, NBL>(b, g, E, vA, vB, red);
+        QPX_PROF(3)
+        T mu = 0, feas = 0, resid = 0, szdot = 0;
+        if (w0) {
+            T pri2 = 0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) {
+                    const T rz = s[k] - vC[i] - vB[i];
+                    pri2 = fma_(rz, rz, pri2);
+                    szdot = fma_(s[k], z[k], szdot);
+                    vD[i] = s[k] / z[k];
+                    vRH[i] = vC[i] + vB[i] + tau * sigz * vR1[i];       // affine right-hand side c + R z
+                }
+            }
+            pri2 = wave_sum(b, pri2);
+            szdot = wave_sum(b, szdot);
+            mu = abs_(szdot / mT);
+            const T pri = sqrt_(pri2);
+            const T dual = tau * sigz * g1n;
+            feas = pri + dual;
+            resid = feas + mT * mu;
+            if (a.trace && lane == 0) {
+                T* tr = a.trace + ((size_t)it * a.B + qp) * 3;
+                tr[0] = pri; tr[1] = dual; tr[2] = mu;
+            }
+        }
+        GridPos<GS>::sync(b);
+        grid_add_diag<T, GS, NBL>(g, E, vD);
+        QPX_PROF(4)
+        ok = grid_ldl_inv<T, GS, NBL>(b, g, E, vec2, dsl, rd, m);
+        QPX_PROF(5)
+        if (w0) {
+            int stopf = 0;
+            if (!ok) {
+                st |= QPX_ST_KKT_BREAKDOWN;
+                stopf = 1;
+            } else {
+                iters = it + 1;
+                const bool better = (it == 0) || (resid < bres);
+                if (better) {
+                    bres = resid; btau = tau; nnot = 0;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const int i = k * kWave + lane;
+                        if (i < m) { vBZ[i] = z[k]; vBS[i] = s[k]; }
+                    }
+                } else if (a.stall_policy == 1 || (a.stall_policy == 2 && mT * mu < feas)) {
+                    nnot += 1;
+                } else {
+                    nnot = 0;
+                }
+                if (a.stall_policy == 2 && it >= 1 && feas > T(2) * (T(1) - alpha_prev) * feas_prev) floor_hit = 1;
+                feas_prev = feas;
+                if ((a.stall_policy != 0 && nnot >= a.notImprovedLim) || bres < a.eps || mu > T(1e32)) stopf = 1;
+                if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-4) * feas) stopf = 1;
+                if (!finite_(resid)) { stopf = 1; st |= QPX_ST_NONFINITE; }
+            }
+            if (lane == 0) ctrl[0] = stopf;
+        }
+        GridPos<GS>::sync(b);
+        stop = ctrl[0];
+        if (stop) break;
+        // affine scaling direction: dz_aff = -T^-1 (c + R z)
+        grid_solve_neg<T, GS, NBL>(b, g, E, rd, m, vRH, vX, vTm, red);
+        T dza[NS], dsa[NS], rs[NS];
+        if (w0) {
+            ld_slots<NS>(b, dza, vX, m, T(0));
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                dsa[k] = (i < m) ? (-s[k] - dza[k] * s[k] / z[k]) : T(0);
+            }
+            T al = step_to_boundary<NS>(b, z, dza, m);
+            const T al2 = step_to_boundary<NS>(b, s, dsa, m);
+            al = (al2 < al) ? al2 : al;
+            al = (al < T(1)) ? al : T(1);
+            T t3 = 0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) t3 = fma_(s[k] + al * dsa[k], z[k] + al * dza[k], t3);
+            }
+            t3 = wave_sum(b, t3);
+            T sig = t3 / szdot;
+            sig = sig * sig * sig;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                rs[k] = (i < m) ? ((-mu * sig + dsa[k] * dza[k]) / s[k]) : T(0);
+                if (i < m) vRH[i] = rs[k] * s[k] / z[k];
+            }
+        }
+        GridPos<GS>::sync(b);
+        grid_solve_neg<T, GS, NBL>(b, g, E, rd, m, vRH, vX, vTm, red);
+        if (w0) {
+            T dz[NS], ds[NS];
+            ld_slots<NS>(b, dz, vX, m, T(0));
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                const T dsc = (i < m) ? ((-rs[k] - dz[k]) * s[k] / z[k]) : T(0);
+                dz[k] = (i < m) ? (dza[k] + dz[k]) : T(0);
+                ds[k] = dsa[k] + dsc;
+            }
+            T al = step_to_boundary<NS>(b, z, dz, m);
+            const T al3 = step_to_boundary<NS>(b, s, ds, m);
+            al = (al3 < al) ? al3 : al;
+            al = T(0.999) * al;
+            al = (al < T(1)) ? al : T(1);
+            tau = (T(1) - al) * tau;
+            alpha_prev = al;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) {
+                    z[k] = fma_(al, dz[k], z[k]);
+                    s[k] = fma_(al, ds[k], s[k]);
+                    vA[i] = z[k] - tau * sigz;
+                }
+            }
+        }
+        GridPos<GS>::sync(b);
+        QPX_PROF(6)
+    }
+
+    // ---- outputs (batch.py:143,207)
+    if (w0) {
+        if (iters >= a.maxIter && !(bres < a.eps)) st |= QPX_ST_MAXITER;
+        if (!(bres <= T(1))) st |= QPX_ST_INACCURATE;
+        for (int i = lane; i < m; i += kWave) {
+            const T bz = vBZ[i];
+            a.lam[(size_t)qp * m + i] = bz;
+            a.slack[(size_t)qp * m + i] = vBS[i];
+            vA[i] = bz - btau * sigz;
+        }
+        if (lane == 0) {
+            a.iters[qp] = iters;
+            a.status[qp] |= st;
+            a.best_resid[qp] = bres;
+        }
+    }
+    if (q > 0)
+        for (int i = b.tid; i < q; i += NT) vTm[i] = bg[i];
+    GridPos<GS>::sync(b);
+    // zhat = x0 - M^T z' = -K p + N b - M^T z'
+    block_matTvec<T, 0>(b, vX, F + lay.Kneg, vP, n, n);
+    GridPos<GS>::sync(b);
+    block_matTvec<T, 2>(b, vX, F + lay.M, vA, m, n);
+    if (q > 0) {
+        GridPos<GS>::sync(b);
+        block_matTvec<T, 2>(b, vX, F + lay.NTn, vTm, q, n);
+    }
+    GridPos<GS>::sync(b);
+    for (int i = b.tid; i < n; i += NT) a.zhat[(size_t)qp * n + i] = vX[i];
+    if (q > 0) {
+        // nu = -S11^-1 b + NTn p - W^T z'
+        for (int r = b.tid; r < q; r += NT) {
+            T acc = 0;
+            for (int c2 = 0; c2 < q; ++c2) acc = fma_(-F[lay.S11i + (size_t)r * q + c2], vTm[c2], acc);
+            for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], vP[k], acc);
+            for (int j = 0; j < m; ++j) acc = fma_(-F[lay.W + (size_t)j * q + r], vA[j], acc);
+            a.nu[(size_t)qp * q + r] = acc;
+        }
+    }
+    QPX_PROF(7)
+    QPX_PROF_DUMP(a.trace ? a.trace + (size_t)qp * 8 : (T*)nullptr, T)
+}
+
+// ------------------------------------------------------------------------------------------
+// factor_kkt + solve_kkt for arbitrary right-hand sides and QPFunctionFn.backward on the
+// format-3 blob (see kkt_body for the reference citations):
+//   dz = -T^-1 (M rx + W ry + rs/d - rz),  dx = -K rx - M^T dz - N ry,
+//   dy = S11^-1 ry - N^T rx - W^T dz,      ds = (-rs - dz)/d
+template <class T, int GS, int NBL, bool kBackward>
+QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
+{
+    constexpr int M8 = GS * NBL, NT = GS * GS;
+    const GridPos<GS> g(b);
+    const int n = a.n, m = a.m, q = a.q;
+    const FacLayout lay = fac_layout(n, m, q);
+    T* F = a.fac + (size_t)qp * a.fac_stride;
+    const size_t v = align4(max2(max2((size_t)n, (size_t)M8), (size_t)q));
+    T* rd = lds;
+    T* vD = rd + v;       // 1/d, 1 on the pad
+    T* vRX = vD + v;      // rx (n)
+    T* vRY = vRX + v;     // ry (q)
+    T* vRH = vRY + v;     // right-hand side of the solve (M8)
+    T* vDZ = vRH + v;     // dz (M8)
+    T* vTm = vDZ + v;
+    T* vDX = vTm + v;     // dx (n)
+    T* vDY = vDX + v;     // dy (q)
+    T* vZH = vDY + v;     // zhat (n)   [backward]
+    T* vLM = vZH + v;     // lam (m)    [backward]
+    T* vNU = vLM + v;     // nu (q)     [backward]
+    T* vec2 = vNU + v;
+    T* dsl = vec2 + 2 * M8;
+    T* red = dsl + 8;
+
+    const T* rxg = kBackward ? (a.dl_dz + (size_t)qp * n) : (a.rx ? a.rx + (size_t)qp * n : nullptr);
+    const T* rsg = (!kBackward && a.rs) ? a.rs + (size_t)qp * m : nullptr;
+    const T* rzg = (!kBackward && a.rz) ? a.rz + (size_t)qp * m : nullptr;
+    const T* ryg = (!kBackward && a.ry && q > 0) ? a.ry + (size_t)qp * q : nullptr;
+
+    for (int i = b.tid; i < n; i += NT) vRX[i] = rxg ? rxg[i] : T(0);
+    for (int i = b.tid; i < q; i += NT) vRY[i] = ryg ? ryg[i] : T(0);
+    for (int i = b.tid; i < M8; i += NT) {
+        T dinv = T(1), rhs = T(0);
+        if (i < m) {
+            T d;
+            if (kBackward) {
+                const T l = a.lam[(size_t)qp * m + i], sl = a.slack[(size_t)qp * m + i];
+                d = ((l < T(1e-8)) ? T(1e-8) : l) / ((sl < T(1e-8)) ? T(1e-8) : sl);      // qp.py:148
+            } else {
+                d = a.d[(size_t)qp * m + i];
+            }
+            dinv = T(1) / d;
+            rhs = (rsg ? rsg[i] * dinv : T(0)) - (rzg ? rzg[i] : T(0));
+        }
+        vD[i] = dinv;
+        vRH[i] = rhs;
+    }
+    GridPos<GS>::sync(b);
+    // rhs += M rx + W ry
+    block_matTvec<T, 1>(b, vRH, F + lay.MT, vRX, n, m);
+    if (q > 0) {
+        GridPos<GS>::sync(b);
+        for (int j = b.tid; j < m; j += NT) {
+            T acc = vRH[j];
+            for (int r = 0; r < q; ++r) acc = fma_(F[lay.W + (size_t)j * q + r], vRY[r], acc);
+            vRH[j] = acc;
+        }
+    }
+    T E[gtri(NBL)];
+    grid_load<T, GS, NBL>(b, E, F + lay.Rg);
+    GridPos<GS>::sync(b);
+    grid_add_diag<T, GS, NBL>(g, E, vD);
+    const bool ok = grid_ldl_inv<T, GS, NBL>(b, g, E, vec2, dsl, rd, m);
+    if (!ok && b.tid == 0 && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
+    if (ok) grid_solve_neg<T, GS, NBL>(b, g, E, rd, m, vRH, vDZ, vTm, red);
+    else {
+        for (int i = b.tid; i < M8; i += NT) vDZ[i] = T(0);
+        GridPos<GS>::sync(b);
+    }
+    // dx = Kneg rx - M^T dz + NTn^T ry     (Kneg = -K, NTn = -N^T)
+    block_matTvec<T, 0>(b, vDX, F + lay.Kneg, vRX, n, n);
+    GridPos<GS>::sync(b);
+    block_matTvec<T, 2>(b, vDX, F + lay.M, vDZ, m, n);
+    if (q > 0) {
+        GridPos<GS>::sync(b);
+        block_matTvec<T, 1>(b, vDX, F + lay.NTn, vRY, q, n);
+        // dy = S11i ry + NTn rx - W^T dz
+        for (int r = b.tid; r < q; r += NT) {
+            T acc = 0;
+            for (int c2 = 0; c2 < q; ++c2) acc = fma_(F[lay.S11i + (size_t)r * q + c2], vRY[c2], acc);
+            for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], vRX[k], acc);
+            for (int j = 0; j < m; ++j) acc = fma_(-F[lay.W + (size_t)j * q + r], vDZ[j], acc);
+            vDY[r] = acc;
+        }
+    }
+    GridPos<GS>::sync(b);
+    if (!kBackward) {
+        for (int i = b.tid; i < n; i += NT) a.dx[(size_t)qp * n + i] = vDX[i];
+        for (int i = b.tid; i < m; i += NT) {
+            a.dz[(size_t)qp * m + i] = vDZ[i];
+            a.ds[(size_t)qp * m + i] = (-(rsg ? rsg[i] : T(0)) - vDZ[i]) * vD[i];
+        }
+        for (int i = b.tid; i < q; i += NT) a.dy[(size_t)qp * q + i] = vDY[i];
+        return;
+    }
+    // ---- gradients (qp.py:157-173)
+    for (int i = b.tid; i < n; i += NT) {
+        vZH[i] = a.zhat[(size_t)qp * n + i];
+        a.dp[(size_t)qp * n + i] = vDX[i];
+    }
+    for (int i = b.tid; i < m; i += NT) {
+        vLM[i] = a.lam[(size_t)qp * m + i];
+        a.dh[(size_t)qp * m + i] = -vDZ[i];
+    }
+    for (int i = b.tid; i < q; i += NT) {
+        vNU[i] = a.nu[(size_t)qp * q + i];
+        a.db[(size_t)qp * q + i] = -vDY[i];
+    }
+    GridPos<GS>::sync(b);
+    T* dQ = a.dQ + (size_t)qp * n * n;
+    for (int idx = b.tid; idx < n * n; idx += NT) {
+        const int r = idx / n, c = idx - r * n;
+        dQ[idx] = T(0.5) * (vDX[r] * vZH[c] + vZH[r] * vDX[c]);
+    }
+    T* dG = a.dG + (size_t)qp * m * n;
+    for (int idx = b.tid; idx < m * n; idx += NT) {
+        const int r = idx / n, c = idx - r * n;
+        dG[idx] = vDZ[r] * vZH[c] + vLM[r] * vDX[c];
+    }
+    if (q > 0) {
+        T* dA = a.dA + (size_t)qp * q * n;
+        for (int idx = b.tid; idx < q * n; idx += NT) {
+            const int r = idx / n, c = idx - r * n;
+            dA[idx] = vDY[r] * vZH[c] + vNU[r] * vDX[c];
+        }
+    }
+}
+
+QPX_LAYOUT_HD size_t lds_elems_kkt_grid(int gs, int nbl, int n, int q)
+{
+    const size_t mg = (size_t)gs * nbl;
+    const size_t v = align4(max2(max2((size_t)n, mg), (size_t)q));
+    return 12 * v + 2 * mg + 8 + (size_t)nbl * gs * gs;
+}
+
+}  // namespace qpx

@@ -5,7 +5,8 @@
 // do not fit.  Kernels are stream-ordered, allocate nothing and never synchronise the host.
 //
 // Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm (workgroup per QP),
-// 3 = kkt/backward, 4 = ipm (wave per QP).
+// 3 = kkt/backward, 4 = ipm (wave per QP), 5 = sweep pre-factorisation (16x16 thread grid),
+// 6 = ipm (thread grid), 7 = kkt/backward (thread grid).
 #include <hip/hip_runtime.h>
 
 #include "../../include/qpx.h"
@@ -106,9 +107,65 @@ int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
 #define QPX_INSTW(NB, NS) \
     template int launch_ipm_wave<QPX_TU_REAL, NB, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTW(2, 1) QPX_INSTW(2, 2) QPX_INSTW(4, 1) QPX_INSTW(4, 2) QPX_INSTW(8, 1) QPX_INSTW(8, 2) QPX_INSTW(13, 2)
+#elif QPX_TU_KERNEL == 5
+template <class T, int NBL> __global__ __launch_bounds__(256) void k_sweep(PrefactorArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    sweep_body<T, NBL>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_sweep<T, NBL>;
+    static bool big_lds_enabled = false;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTG(NBL) template int launch_sweep<QPX_TU_REAL, NBL>(const PrefactorArgs<QPX_TU_REAL>&, size_t, void*);
+QPX_INSTG(1) QPX_INSTG(2) QPX_INSTG(4) QPX_INSTG(7) QPX_INSTG(10) QPX_INSTG(13)
+#elif QPX_TU_KERNEL == 6
+// two workgroups per CU (2 waves per SIMD) for the common sizes: the two QPs hide each other's
+// barrier / LDS latencies
+template <class T, int NBL, int NS> __global__ __launch_bounds__(256, (NBL <= 7 ? 2 : 1)) void k_ipm_grid(IpmArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    ipm_grid_body<T, 16, NBL, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_ipm_grid<T, NBL, NS>;
+    static bool big_lds_enabled = false;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTG(NBL, NS) template int launch_ipm_grid<QPX_TU_REAL, NBL, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
+QPX_INSTG(1, 1) QPX_INSTG(1, 2) QPX_INSTG(1, 4) QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(2, 4)
+QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(4, 4) QPX_INSTG(7, 2) QPX_INSTG(7, 4) QPX_INSTG(10, 4) QPX_INSTG(13, 4)
+#elif QPX_TU_KERNEL == 7
+template <class T, int NBL, bool kBw> __global__ __launch_bounds__(256, (NBL <= 7 ? 2 : 1)) void k_kkt_grid(KktArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    kkt_grid_body<T, 16, NBL, kBw>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_kkt_grid<T, NBL, kBw>;
+    static bool big_lds_enabled = false;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTG(NBL)                                                                              \
+    template int launch_kkt_grid<QPX_TU_REAL, NBL, false>(const KktArgs<QPX_TU_REAL>&, size_t, void*); \
+    template int launch_kkt_grid<QPX_TU_REAL, NBL, true>(const KktArgs<QPX_TU_REAL>&, size_t, void*);
+QPX_INSTG(1) QPX_INSTG(2) QPX_INSTG(4) QPX_INSTG(7) QPX_INSTG(10) QPX_INSTG(13)
 #endif
 
-#if QPX_TU_KERNEL != 4
+#if QPX_TU_KERNEL >= 1 && QPX_TU_KERNEL <= 3
 QPX_INST(1, true) QPX_INST(1, false) QPX_INST(2, true) QPX_INST(2, false)
 QPX_INST(4, true) QPX_INST(4, false) QPX_INST(8, true) QPX_INST(8, false)
 #endif

@@ -359,6 +359,7 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
         Lq = F + lay.L; Z = F + lay.Zp; Yh = F + lay.Yh; V = F + lay.V; L11 = F + lay.L11;
     }
 
+    QPX_PROF_INIT
     // register-layout copy of R for the wave-per-QP kernel: zero it first (padding, upper parts)
     if (lay.nbw > 0)
         for (size_t e = b.tid; e < (size_t)(lay.nbw * (lay.nbw + 1) / 2) * 64; e += b.nt) F[lay.Rw + e] = T(0);
@@ -375,6 +376,7 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
         if (b.tid == 0) a.status[qp] = QPX_ST_Q_NOT_SPD;
         return;
     }
+    QPX_PROF(0)
     // C. Z = G^T  (n x m), padded columns zero
     for (int idx = b.tid; idx < n * ldz; idx += b.nt) {
         const int i = idx / ldz, j = idx - i * ldz;
@@ -399,10 +401,12 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
         acc = wave_sum(b, acc);
         if (b.lane() == 0) F[lay.scal] = sqrt_(acc);
     }
+    QPX_PROF(1)
     // D. Z <- L^-1 G^T ; Y <- L^-1 A^T
     block_trsm_lower(b, Lq, dq, n, Z, ldz, m);
     if (q > 0) block_trsm_lower(b, Lq, dq, n, Yh, q, q);
     b.sync();
+    QPX_PROF(2)
     int okA = 1;
     if (q > 0) {
         // E. S11 = Y^T Y -> L11 ; Yh = Y L11^-T ; V = Yh^T Z ; Zp = Z - Yh V
@@ -445,6 +449,7 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
         }
         b.sync();
     }
+    QPX_PROF(3)
     // F. R = Zp^T Zp, packed lower, straight to HBM; 4x4 register tiles
     {
         T* Rg = F + lay.R;
@@ -487,6 +492,8 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
                 }
         }
     }
+    b.sync();
+    QPX_PROF(4)
     // G. r1 = R 1 = Zp^T (Zp 1)
     for (int k = b.tid; k < n; k += b.nt) {
         T acc = 0;
@@ -518,6 +525,9 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
         }
     }
     if (b.tid == 0) a.status[qp] = 0;
+    b.sync();
+    QPX_PROF(5)
+    QPX_PROF_DUMP(F + lay.T, T)
 }
 
 // ------------------------------------------------------------------------------------------

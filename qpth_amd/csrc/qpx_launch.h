@@ -7,6 +7,7 @@
 
 #include "qpx_kernels.h"
 #include "qpx_wave.h"
+#include "qpx_grid.h"
 
 namespace qpx {
 
@@ -26,5 +27,10 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream);
 // wave-per-QP PDIPM loop (qpx_wave.h): workgroup = one wave64
 template <class T, int NB, int NS>
 int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
+
+// thread-grid kernels (qpx_grid.h), 16x16 threads per QP, format-3 blob
+template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream);
+template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
+template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void* stream);
 
 }  // namespace qpx

@@ -48,9 +48,31 @@ QPX_LAYOUT_HD int wave_nb(int m)
     return 0;
 }
 
+// Blocks of 16 rows the 16x16 thread-grid kernels (qpx_grid.h) use for a matrix of order `ord`
+// (0: not instantiated for this size).
+QPX_LAYOUT_HD int grid_nb(int ord)
+{
+    const int need = (ord + 15) / 16;
+    if (need <= 1) return 1;
+    if (need <= 2) return 2;
+    if (need <= 4) return 4;
+    if (need <= 7) return 7;
+    if (need <= 10) return 10;
+    if (need <= 13) return 13;
+    return 0;
+}
+
 struct FacLayout {
-    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, Rw, total;
-    int nbw;
+    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, Rw;
+    // "format 3" (grid kernels: sweep pre-factorisation, no triangular factors), present when
+    // grid_nb(n+q+m) > 0:  Kneg = -K (n x n, full), M = G K (m x n), MT = M^T (n x m),
+    // NTn = -N^T = -(A K')... (q x n), W = G N (m x q), S11i = (A Q^-1 A^T)^-1 (q x q),
+    // Rg = R in the 16x16 grid register layout (gtri(nbg) * 256)
+    size_t Kneg, M, MT, NTn, W, S11i, Rg;
+    size_t total;
+    int nbw;      // wave kernel blocks of 8 for m (0 = n/a)
+    int nbg;      // grid blocks of 16 for m
+    int nba;      // grid blocks of 16 for the augmented order n+q+m (0 = format 3 unavailable)
 };
 
 QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
@@ -70,6 +92,18 @@ QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
     f.T = o;      o += align4(tri(m));
     f.nbw = wave_nb(m);
     f.Rw = o;     o += (size_t)(f.nbw * (f.nbw + 1) / 2) * 64;
+    f.nba = grid_nb(n + q + m);
+    f.nbg = f.nba > 0 ? grid_nb(m) : 0;
+    f.Kneg = f.M = f.MT = f.NTn = f.W = f.S11i = f.Rg = o;
+    if (f.nba > 0) {
+        f.Kneg = o; o += align4((size_t)n * n);
+        f.M = o;    o += align4((size_t)m * n);
+        f.MT = o;   o += align4((size_t)n * m);
+        f.NTn = o;  o += align4((size_t)q * n);
+        f.W = o;    o += align4((size_t)m * q);
+        f.S11i = o; o += align4((size_t)q * q);
+        f.Rg = o;   o += (size_t)(f.nbg * (f.nbg + 1) / 2) * 256;
+    }
     f.total = o;
     return f;
 }

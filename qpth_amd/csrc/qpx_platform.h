@@ -98,6 +98,21 @@ template <class T> QPX_DEV T fma_(T a, T b, T c);
 template <> QPX_DEV float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <> QPX_DEV double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// 1/x to full precision from the hardware estimate + Newton steps (the IEEE division sequence
+// of `1.0/x` is ~3x longer and sits on the critical chain of every LDL column)
+QPX_DEV float rcp_(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    r = __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
+    return r;
+}
+QPX_DEV double rcp_(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return r;
+}
 QPX_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
 QPX_DEV double sqrt_(double x) { return __builtin_sqrt(x); }
 QPX_DEV float abs_(float x) { return __builtin_fabsf(x); }

@@ -90,33 +90,51 @@ template <class T, int NB> QPX_DEV void wave_add_diag(const Block& b, T (&Tr)[wa
     }
 }
 
-// One column step of the register-resident LDL^T (column k = 8*KB + ka); KBN = block column of
-// column k+1 (KB, or KB+1 when ka == 7).  Returns false on a non-positive / non-finite pivot.
+// State carried from one column step to the next (software pipeline): the un-scaled entries of
+// the NEXT pivot column this lane needs, fetched from LDS while the bulk of the current rank-1
+// update executes.
+template <class T, int NB> struct LdlCarry {
+    T lrow[NB];   // c_ik for rows i = 8*l + a          (l >= block of the column)
+    T lcA, lcB;   // c_jk for row j = 8*KB + b and j = 8*(KB+1) + b
+    T dk;         // pivot d_k
+};
+
+template <class T, int NB, int KB>
+QPX_DEV void wave_ldl_fetch(const T* Lc, int kn, int a, int bb, LdlCarry<T, NB>& c)
+{
+    // column kn (belonging to block KB or starting block KB): rows are read from block KB on
+    constexpr int M8 = 8 * NB;
+    const int offn = wcol_off(kn, M8);
+    const int base = offn - kn;
+#pragma unroll
+    for (int l = KB; l < NB; ++l) c.lrow[l] = Lc[base + 8 * l + a];
+    c.lcA = Lc[base + 8 * KB + bb];
+    c.lcB = (KB + 1 < NB) ? Lc[base + 8 * (KB + 1) + bb] : T(0);
+    c.dk = Lc[offn];
+}
+
+// One column step (column k = 8*KB + ka); KBN = block column of column k+1 (KB, or KB+1 when
+// ka == 7).  `c` holds column k on entry and column k+1 on exit.  Returns false on a
+// non-positive / non-finite pivot.
 template <class T, int NB, int KB, int KBN>
-QPX_DEV bool wave_ldl_step(const Block& b, T (&Tr)[wave_tri(NB)], T* Lc, T* rd, int ka)
+QPX_DEV bool wave_ldl_step(const Block& b, T (&Tr)[wave_tri(NB)], T* Lc, T* rd, int ka, LdlCarry<T, NB>& c)
 {
     constexpr int M8 = 8 * NB;
     const int lane = b.lane(), a = lane & 7, bb = lane >> 3;
     const int k = 8 * KB + ka;
-    const int offk = wcol_off(k, M8);
-    const int base = offk - k;                     // row i of column k sits at base + i  (i >= k)
-    T lrow[NB + 1];
-#pragma unroll
-    for (int l = KBN; l < NB; ++l) lrow[l] = Lc[base + 8 * l + a];
-    const T dk = Lc[offk];
+    const int base = wcol_off(k, M8) - k;          // row i of column k sits at base + i  (i >= k)
+    const T dk = c.dk;
     if (!(dk > T(0)) || !finite_(dk)) return false;
-    const T r = T(1) / dk;
+    const T r = rcp_(dk);
     if (lane == 0) rd[k] = r;
+    T lrs[NB + 1];
 #pragma unroll
-    for (int l = KBN; l < NB; ++l) lrow[l] *= r;
-    if (KBN < NB) {
+    for (int l = KBN; l < NB; ++l) lrs[l] = c.lrow[l] * r;
+    if constexpr (KBN < NB) {
         // look-ahead: finish the block column that holds column k+1 and publish that column
-        {
-            const T lc = Lc[base + 8 * KBN + bb];
+        const T lc0 = (KBN == KB) ? c.lcA : c.lcB;
 #pragma unroll
-            for (int li = KBN; li < NB; ++li)
-                Tr[widx(li, KBN)] = fma_(-lrow[li], lc, Tr[widx(li, KBN)]);
-        }
+        for (int li = KBN; li < NB; ++li) Tr[widx(li, KBN)] = fma_(-lrs[li], lc0, Tr[widx(li, KBN)]);
         const int kn = k + 1;
         const int kan = kn & 7;
         const int offn = wcol_off(kn, M8) - kn;
@@ -127,134 +145,161 @@ QPX_DEV bool wave_ldl_step(const Block& b, T (&Tr)[wave_tri(NB)], T* Lc, T* rd, 
                 if (i >= kn) Lc[offn + i] = Tr[widx(li, KBN)];
             }
         }
-        // bulk of the rank-1 update
+        b.wave_sync();
+        // software pipeline: the reads of column k+1 go out now and land during the bulk update
+        wave_ldl_fetch<T, NB, KBN>(Lc, kn, a, bb, c);
+        // bulk of the rank-1 update with column k
 #pragma unroll
         for (int lj = KBN + 1; lj < NB; ++lj) {
-            const T lc = Lc[base + 8 * lj + bb];      // column value, fetched per block column
+            const T lc = Lc[base + 8 * lj + bb];
 #pragma unroll
-            for (int li = lj; li < NB; ++li)
-                Tr[widx(li, lj)] = fma_(-lrow[li], lc, Tr[widx(li, lj)]);
+            for (int li = lj; li < NB; ++li) Tr[widx(li, lj)] = fma_(-lrs[li], lc, Tr[widx(li, lj)]);
         }
     }
-    b.wave_sync();
     return true;
 }
 
 template <class T, int NB, int KB> struct WaveLdlBlocks {
-    static QPX_DEV bool run(const Block& b, T (&Tr)[wave_tri(NB)], T* Lc, T* rd)
+    static QPX_DEV bool run(const Block& b, T (&Tr)[wave_tri(NB)], T* Lc, T* rd, LdlCarry<T, NB>& c)
     {
 #pragma unroll 1
         for (int ka = 0; ka < 7; ++ka)
-            if (!wave_ldl_step<T, NB, KB, KB>(b, Tr, Lc, rd, ka)) return false;
-        if (!wave_ldl_step<T, NB, KB, KB + 1>(b, Tr, Lc, rd, 7)) return false;
-        return WaveLdlBlocks<T, NB, KB + 1>::run(b, Tr, Lc, rd);
+            if (!wave_ldl_step<T, NB, KB, KB>(b, Tr, Lc, rd, ka, c)) return false;
+        if (!wave_ldl_step<T, NB, KB, KB + 1>(b, Tr, Lc, rd, 7, c)) return false;
+        return WaveLdlBlocks<T, NB, KB + 1>::run(b, Tr, Lc, rd, c);
     }
 };
 template <class T, int NB> struct WaveLdlBlocks<T, NB, NB> {
-    static QPX_DEV bool run(const Block&, T (&)[wave_tri(NB)], T*, T*) { return true; }
+    static QPX_DEV bool run(const Block&, T (&)[wave_tri(NB)], T*, T*, LdlCarry<T, NB>&) { return true; }
 };
 
-// T = L~ D L~^T.  On return Lc holds, packed by columns, d_k (diagonal) and c_ik = l~_ik d_k
-// (below it); rd[k] = 1/d_k.  The registers are consumed.
-template <class T, int NB> QPX_DEV bool wave_ldl(const Block& b, T (&Tr)[wave_tri(NB)], T* Lc, T* rd)
+// T = L~ D L~^T.  On return Lc holds the UNIT lower factor packed by columns (l~_ik below the
+// diagonal; the diagonal slots keep d_k) and rd[k] = 1/d_k.  The registers are consumed.
+template <class T, int NB>
+QPX_DEV bool wave_ldl(const Block& b, T (&Tr)[wave_tri(NB)], T* Lc, T* rd, int m)
 {
+    constexpr int M8 = 8 * NB;
     const int lane = b.lane(), a = lane & 7, bb = lane >> 3;
     if (bb == 0) {
 #pragma unroll
         for (int li = 0; li < NB; ++li) Lc[8 * li + a] = Tr[widx(li, 0)];      // column 0
     }
     b.wave_sync();
-    return WaveLdlBlocks<T, NB, 0>::run(b, Tr, Lc, rd);
+    LdlCarry<T, NB> c;
+    wave_ldl_fetch<T, NB, 0>(Lc, 0, a, bb, c);
+    if (!WaveLdlBlocks<T, NB, 0>::run(b, Tr, Lc, rd, c)) return false;
+    b.wave_sync();
+    // scale column k by 1/d_k: the substitutions then carry no multiply in their dependent chain
+    for (int k = 0; k + 1 < m; ++k) {
+        const T r = rd[k];
+        const int off = wcol_off(k, M8) - k;
+        for (int i = k + 1 + lane; i < m; i += kWave) Lc[off + i] *= r;
+    }
+    b.wave_sync();
+    return true;
 }
 
-// Solve L~ D u = x in place (x -> u), vector of length m in slot layout (element i in slot i/64
-// of lane i%64).  Column oriented; column k of the packed factor is contiguous.
+// Solve L~ D u = x in place (x -> u), L~ unit lower (column k contiguous), vector of length m in
+// slot layout (element i in slot i/64 of lane i%64).  Dependent chain per step: readlane -> fma.
+// The column entries of the next UNR steps are fetched while the current UNR steps execute.
 template <int NS, class T>
 QPX_DEV void wtrsv_fwd(const Block& b, const T* Lc, const T* rd, int M8, int m, T (&x)[NS])
 {
     constexpr int UNR = 4;
     const int lane = b.lane();
+    const int ngroups = (m + UNR - 1) / UNR;
+    T cur[UNR][NS], nxt[UNR][NS];
+    auto fetch = [&](int g, T (&dst)[UNR][NS]) {
 #pragma unroll
-    for (int sk = 0; sk < NS; ++sk) {
-        const int kbase = sk * kWave;
-        if (kbase < m) {
-            const int kend = (m - kbase < kWave) ? (m - kbase) : kWave;
-            for (int lk0 = 0; lk0 < kend; lk0 += UNR) {
-                T l[UNR][NS];
-                T di[UNR];
+        for (int u = 0; u < UNR; ++u) {
+            const int k = g * UNR + u;
+            const int off = wcol_off(k, M8) - k;
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int k = kbase + lk0 + u;
-                    const bool act = lk0 + u < kend;
-                    const int off = wcol_off(k, M8) - k;
-                    di[u] = act ? rd[k] : T(0);
-#pragma unroll
-                    for (int s2 = sk; s2 < NS; ++s2) {
-                        const int i = s2 * kWave + lane;
-                        l[u][s2] = (act && i > k && i < m) ? Lc[off + i] : T(0);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int lk = lk0 + u;
-                    if (lk < kend) {
-                        const T uk = b.bcast(x[sk], lk) * di[u];
-                        if (lane == lk) x[sk] = uk;
-#pragma unroll
-                        for (int s2 = sk; s2 < NS; ++s2) x[s2] = fma_(-l[u][s2], uk, x[s2]);
-                    }
-                }
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const int i = s2 * kWave + lane;
+                const bool v = (k < m) && (i > k) && (i < m);
+                const T val = Lc[v ? off + i : 0];
+                dst[u][s2] = v ? val : T(0);
             }
         }
+    };
+    fetch(0, cur);
+    for (int g = 0; g < ngroups; ++g) {
+        if (g + 1 < ngroups) fetch(g + 1, nxt);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int k = g * UNR + u;
+            if (k < m) {
+                const int sk = k >> 6, lk = k & 63;
+                T yk = T(0);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (s == sk) yk = b.bcast(x[s], lk);
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) x[s2] = fma_(-cur[u][s2], yk, x[s2]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) cur[u][s2] = nxt[u][s2];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = s * kWave + lane;
+        x[s] = (i < m) ? x[s] * rd[i] : T(0);
     }
 }
 
-// Solve L~^T y = u in place.  Row k of the packed factor is read per step (lane j reads c_kj).
+// Solve L~^T y = u in place.  Row k of the packed factor is read per step (lane j reads l~_kj).
 template <int NS, class T>
 QPX_DEV void wtrsv_bwd(const Block& b, const T* Lc, const T* rd, int M8, int m, T (&x)[NS])
 {
     constexpr int UNR = 4;
     const int lane = b.lane();
-    T w[NS], rdl[NS];
+    const int ngroups = (m + UNR - 1) / UNR;
     int offj[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int j = s * kWave + lane;
-        w[s] = T(0);
-        rdl[s] = (j < m) ? rd[j] : T(0);
-        offj[s] = wcol_off(j, M8) - j;            // c_kj sits at offj + k  (k >= j)
+        offj[s] = (j < m) ? (wcol_off(j, M8) - j) : 0;     // l~_kj sits at offj + k  (k > j)
     }
+    T cur[UNR][NS], nxt[UNR][NS];
+    auto fetch = [&](int g, T (&dst)[UNR][NS]) {
 #pragma unroll
-    for (int sk = NS - 1; sk >= 0; --sk) {
-        const int kbase = sk * kWave;
-        if (kbase < m) {
-            const int kend = (m - kbase < kWave) ? (m - kbase) : kWave;
-            for (int lk0 = kend - 1; lk0 >= 0; lk0 -= UNR) {
-                T l[UNR][NS];
+        for (int u = 0; u < UNR; ++u) {
+            const int k = m - 1 - (g * UNR + u);
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int lk = lk0 - u;
-                    const int k = kbase + lk;
-#pragma unroll
-                    for (int s2 = 0; s2 <= sk; ++s2) {
-                        const int j = s2 * kWave + lane;
-                        l[u][s2] = (lk >= 0 && j < k) ? Lc[offj[s2] + k] : T(0);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int lk = lk0 - u;
-                    if (lk >= 0) {
-                        const T cand = fma_(-rdl[sk], w[sk], x[sk]);
-                        const T yk = b.bcast(cand, lk);
-                        if (lane == lk) x[sk] = yk;
-#pragma unroll
-                        for (int s2 = 0; s2 <= sk; ++s2) w[s2] = fma_(l[u][s2], yk, w[s2]);
-                    }
-                }
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const int j = s2 * kWave + lane;
+                const bool v = (k >= 0) && (j < k);
+                const T val = Lc[v ? offj[s2] + k : 0];
+                dst[u][s2] = v ? val : T(0);
             }
         }
+    };
+    fetch(0, cur);
+    for (int g = 0; g < ngroups; ++g) {
+        if (g + 1 < ngroups) fetch(g + 1, nxt);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int k = m - 1 - (g * UNR + u);
+            if (k >= 0) {
+                const int sk = k >> 6, lk = k & 63;
+                T yk = T(0);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (s == sk) yk = b.bcast(x[s], lk);
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) x[s2] = fma_(-cur[u][s2], yk, x[s2]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) cur[u][s2] = nxt[u][s2];
     }
+    (void)rd;
 }
 
 // dz = -T^-1 rhs with T = L~ D L~^T
@@ -381,7 +426,7 @@ QPX_DEV void ipm_wave_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     // ---- start point: T = R + I, z_i = -T^-1 c, s_i = -z_i, shifts (batch.py:61-87)
     wave_load_R<T, NB>(b, Tr, Rw);
     wave_add_diag<T, NB>(b, Tr, vD);
-    bool ok = wave_ldl<T, NB>(b, Tr, Lc, rd);
+    bool ok = wave_ldl<T, NB>(b, Tr, Lc, rd, m);
     int stop = 0;
     if (ok) {
         T x[NS];
@@ -454,7 +499,7 @@ QPX_DEV void ipm_wave_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         b.wave_sync();
         wave_add_diag<T, NB>(b, Tr, vD);
         QPX_PROF(4)
-        ok = wave_ldl<T, NB>(b, Tr, Lc, rd);
+        ok = wave_ldl<T, NB>(b, Tr, Lc, rd, m);
         QPX_PROF(5)
         int stopf = 0;
         if (!ok) {

@@ -22,12 +22,22 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_prof.so"))
     _lib.set_test_backend(lib)        # explicit: route this script's calls to the profiling build
+    lib.dll.qpx_set_ipm_variant(int(os.environ.get("QPX_VARIANT", "0")))
     arrs = problems.prof_qp(B, n, m, q, 0, dt)
     tQ, tp, tG, th, tA, tb = [torch.tensor(x, device=dev) for x in arrs]
     fac = KKTFactors.build(tQ, tG, tA, B)
     for rep in range(3):
         res = fac.ipm(tp, th, tb, want_trace=True)
         torch.cuda.synchronize()
+    from qpth_amd.csrc_layout import fac_layout_T_offset
+    pre = fac.blob.reshape(B, -1)[:, fac_layout_T_offset(n, m, q):][:, :8].double().cpu().numpy()
+    pn = ["load Q + chol(Q)", "load G^T, |G^T 1|", "TRSM Z=L^-1 G^T", "equality block", "SYRK R=Z^T Z", "r1 + spill to blob", "-", "-"]
+    if lib.dll.qpx_set_ipm_variant(int(os.environ.get("QPX_VARIANT", "0"))) is None:
+        pass
+    if int(os.environ.get("QPX_VARIANT", "0")) != 0:
+        print("k_prefactor: total cycles/QP mean %.0f" % pre.sum(1).mean())
+        for i in range(6):
+            print("  %-20s %12.0f cycles (%5.1f%%)" % (pn[i], pre[:, i].mean(), 100 * pre[:, i].sum() / pre.sum()))
     cyc = res.trace.reshape(-1)[:B * 8].reshape(B, 8).double().cpu().numpy()
     iters = res.iters.cpu().numpy()
     tot = cyc.sum(1)

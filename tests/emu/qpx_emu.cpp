@@ -14,6 +14,7 @@
 #include "qpx_platform.h"  // the emulation header: defines QPX_PLATFORM_H, so the HIP one is skipped
 #include "qpx_kernels.h"
 #include "qpx_wave.h"
+#include "qpx_grid.h"
 
 namespace qpx {
 
@@ -118,6 +119,34 @@ int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void*)
         std::vector<unsigned char> lds(lds_bytes + 64);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(kWave, [&](const Block& b) { ipm_wave_body<T, NB, NS>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
+
+template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + 64);
+        T* base = reinterpret_cast<T*>(lds.data());
+        run_block(256, [&](const Block& b) { sweep_body<T, NBL>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
+template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + 64);
+        T* base = reinterpret_cast<T*>(lds.data());
+        run_block(256, [&](const Block& b) { ipm_grid_body<T, 16, NBL, NS>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
+template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + 64);
+        T* base = reinterpret_cast<T*>(lds.data());
+        run_block(256, [&](const Block& b) { kkt_grid_body<T, 16, NBL, kBw>(b, a, qp, base); });
     }
     return QPX_OK;
 }

@@ -67,6 +67,8 @@ template <class T> struct GlobalRows {
 };
 
 template <class T> inline T fma_(T a, T b, T c) { return std::fma(a, b, c); }
+inline float rcp_(float x) { return 1.0f / x; }
+inline double rcp_(double x) { return 1.0 / x; }
 inline float sqrt_(float x) { return std::sqrt(x); }
 inline double sqrt_(double x) { return std::sqrt(x); }
 inline float abs_(float x) { return std::fabs(x); }
