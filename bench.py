@@ -83,6 +83,8 @@ def main():
     tp.requires_grad_(True)                      # prof-linear.py:99
     ones = torch.ones(B, n, dtype=tQ.dtype, device=dev)
     qpf = QPFunction(verbose=-1)
+    if os.environ.get("QPX_VARIANT"):            # A/B knob for kernel development (include/qpx.h)
+        _lib.hip().dll.qpx_set_ipm_variant(int(os.environ["QPX_VARIANT"]))
 
     def step():
         z = qpf(tQ, tp, tG, th, tA, tb)

@@ -86,6 +86,8 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * whenever nz+neq+nineq <= 208, else one 256-thread workgroup per QP with the matrices in LDS
  * (or in HBM when they do not fit); 1 = always the workgroup kernels; 2 = workgroup
  * pre-factorisation/backward + the one-wave-per-QP loop (nineq <= 104, nz <= 128).
+ * Adding 256 / 512 forces the 16x16-thread (four waves per QP) / 8x8-thread (one wave per QP) form of the
+ * grid loop kernel; by default the library picks by batch size.
  * The knob must not change between qpx_pre_factor and the calls that consume its factors.
  * Returns the previous value. */
 int qpx_set_ipm_variant(int variant);

@@ -170,6 +170,22 @@ template <int NB, int MODE> __global__ __launch_bounds__(64) void k_ldl(double* 
     }
 }
 
+// accuracy of rcp_ against IEEE division over many magnitudes
+__global__ void k_rcp_err(double* out, const double* in, int reps)
+{
+    double worst = 0, worst_raw = 0;
+    for (int r = 0; r < reps; ++r) {
+        const double x = ldexp(in[(threadIdx.x + 64 * r) & 4095], (r * 37 + (int)threadIdx.x) % 200 - 100);
+        const double ex = 1.0 / x;
+        const double e1 = __builtin_fabs(rcp_(x) - ex) / __builtin_fabs(ex);
+        const double e0 = __builtin_fabs(__builtin_amdgcn_rcp(x) - ex) / __builtin_fabs(ex);
+        worst = e1 > worst ? e1 : worst;
+        worst_raw = e0 > worst_raw ? e0 : worst_raw;
+    }
+    out[4096 + threadIdx.x] = worst;
+    out[8192 + threadIdx.x] = worst_raw;
+}
+
 extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, const double* in, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
@@ -180,6 +196,7 @@ extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, co
     case 4: hipLaunchKernelGGL(k_lds_roundtrip, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 5: hipLaunchKernelGGL(k_readlane_chain, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 6: hipLaunchKernelGGL(k_rcp_lat, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 9: hipLaunchKernelGGL(k_rcp_err, dim3(1), dim3(64), 0, s, out, in, reps); break;
     case 7: hipLaunchKernelGGL(k_bpermute, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 13: {
         auto k = k_ldl<13, 1>;

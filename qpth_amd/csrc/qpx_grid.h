@@ -109,7 +109,7 @@ QPX_DEV void grid_add_diag(const GridPos<GS>& g, T (&E)[gtri(NBL)], const T* vd)
 
 // One column step of ldl_inv for column k = GS*KB + ka.  `vec` (double buffered by the parity of
 // k) receives: rows i > k: c_ik (un-scaled column k of the Schur complement), cols j < k:
-// W~_kj (row k of the inverse factor, final), entry k: d_k + 1; `dsl[parity]` the pivot d_k.
+// W~_kj (row k of the inverse factor, final), entry k: 0; `dsl[parity]` the pivot d_k.
 template <class T, int GS, int NBL, int KB>
 QPX_DEV bool grid_ldl_inv_step(const Block& blk, const GridPos<GS>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, T* rd, int ka)
 {
@@ -132,7 +132,7 @@ QPX_DEV bool grid_ldl_inv_step(const Block& blk, const GridPos<GS>& g, T (&E)[gt
         }
         if (g.b == ka) {
             const T d = E[gidx(KB, KB)];
-            vec[k] = d + T(1);
+            vec[k] = T(0);
             dsl[k & 1] = d;
         }
     }
@@ -152,7 +152,13 @@ QPX_DEV bool grid_ldl_inv_step(const Block& blk, const GridPos<GS>& g, T (&E)[gt
     for (int lj = 0; lj < NBL; ++lj) {
         const T y = vec[GS * lj + g.b];
 #pragma unroll
-        for (int li = (lj > KB ? lj : KB); li < NBL; ++li) E[gidx(li, lj)] = fma_(-lrow[li], y, E[gidx(li, lj)]);
+        for (int li = (lj > KB ? lj : KB); li < NBL; ++li) {
+            T e = fma_(-lrow[li], y, E[gidx(li, lj)]);
+            // column k itself becomes the new column of W~: W~_ik = -l~_ik, assigned exactly (forming
+            // it as c_ik - l~_ik (d_k + 1) would cancel with relative error eps * d_k)
+            if (lj == KB && g.b == ka && (li > KB || g.a > ka)) e = -lrow[li];
+            E[gidx(li, lj)] = e;
+        }
     }
     return true;
 }
@@ -248,8 +254,7 @@ QPX_DEV void block_matTvec(const Block& blk, T* out, const T* Mat, const T* vec,
 }
 
 // One pivot of the symmetric sweep operator on the register-resident matrix (pivot k = 16*KB + ka):
-//   E_ij -= v_i v_j / d for all i, j  with v = column k (v_k := d - 1, which makes the same
-//   formula produce E_ik = v_i / d),  then E_kk = -1/d.
+//   E_ij -= v_i v_j / d for i, j != k,   E_ik = E_ki = v_i / d,   E_kk = -1/d,   v = column k.
 // Pivots k < npos must be positive (SPD Q), the others negative (-A Q^-1 A^T).
 template <class T, int NBL, int KB>
 QPX_DEV int sweep_step(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, int ka, int npos)
@@ -272,7 +277,7 @@ QPX_DEV int sweep_step(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)]
         }
         if (g.b == ka) {
             const T d = E[gidx(KB, KB)];
-            vec[k] = d - T(1);
+            vec[k] = T(0);
             dsl[k & 1] = d;
         }
     }
@@ -288,7 +293,14 @@ QPX_DEV int sweep_step(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)]
     for (int lj = 0; lj < NBL; ++lj) {
         const T y = vec[GS * lj + g.b];
 #pragma unroll
-        for (int li = lj; li < NBL; ++li) E[gidx(li, lj)] = fma_(-vr[li], y, E[gidx(li, lj)]);
+        for (int li = lj; li < NBL; ++li) {
+            T e = fma_(-vr[li], y, E[gidx(li, lj)]);
+            // row k and column k of the swept matrix are v / d exactly (v_k = 0 leaves them untouched
+            // by the rank-1 update; forming them through it would cancel with relative error eps*d)
+            if (lj == KB && g.b == ka) e = vr[li];                                   // (i, k), any i
+            if (li == KB && g.a == ka) e = vec[GS * lj + g.b] * r;                   // (k, j)
+            E[gidx(li, lj)] = e;
+        }
     }
     if (g.a == ka && g.b == ka) E[gidx(KB, KB)] = -r;
     return 0;
@@ -383,6 +395,7 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
     }
     // ---- scatter the blocks of the swept matrix to the blob
     for (size_t e = blk.tid; e < grid_elems(16, lay.nbg); e += NT) F[lay.Rg + e] = T(0);
+    for (size_t e = blk.tid; e < grid_elems(8, lay.nbw); e += NT) F[lay.Rw + e] = T(0);
     GridPos<GS>::sync(blk);
 #pragma unroll
     for (int li = 0; li < NBL; ++li)
@@ -413,6 +426,12 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
                     T* blkp = F + lay.Rg + (size_t)(l2i * (l2i + 1) / 2 + l2j) * 256;
                     blkp[ai + 16 * bj] = -val;
                     if (l2i == l2j && zi != zj) blkp[bj + 16 * ai] = -val;
+                    if (lay.nbw > 0) {                                           // and of the 8x8 grid
+                        const int w2i = zi >> 3, wa = zi & 7, w2j = zj >> 3, wb = zj & 7;
+                        T* wp = F + lay.Rw + (size_t)(w2i * (w2i + 1) / 2 + w2j) * 64;
+                        wp[wa + 8 * wb] = -val;
+                        if (w2i == w2j && zi != zj) wp[wb + 8 * wa] = -val;
+                    }
                 }
             }
         }
@@ -432,7 +451,7 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     const int n = a.n, m = a.m, q = a.q;
     const FacLayout lay = fac_layout(n, m, q);
     T* F = a.fac + (size_t)qp * a.fac_stride;
-    const T* Rg = F + lay.Rg;
+    const T* Rg = F + (GS == 8 ? lay.Rw : lay.Rg);
     const size_t v = align4(max2(max2((size_t)n, (size_t)M8), (size_t)q));
     T* rd = lds;          // 1/d_k (M8)
     T* vA = rd + v;       // z' (M8)

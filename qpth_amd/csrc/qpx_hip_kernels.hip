@@ -6,7 +6,7 @@
 //
 // Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm (workgroup per QP),
 // 3 = kkt/backward, 4 = ipm (wave per QP), 5 = sweep pre-factorisation (16x16 thread grid),
-// 6 = ipm (thread grid), 7 = kkt/backward (thread grid).
+// 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave).
 #include <hip/hip_runtime.h>
 
 #include "../../include/qpx.h"
@@ -163,6 +163,23 @@ template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, s
     template int launch_kkt_grid<QPX_TU_REAL, NBL, false>(const KktArgs<QPX_TU_REAL>&, size_t, void*); \
     template int launch_kkt_grid<QPX_TU_REAL, NBL, true>(const KktArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTG(1) QPX_INSTG(2) QPX_INSTG(4) QPX_INSTG(7) QPX_INSTG(10) QPX_INSTG(13)
+#elif QPX_TU_KERNEL == 8
+template <class T, int NBL, int NS> __global__ __launch_bounds__(64) void k_ipm_grid8(IpmArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    ipm_grid_body<T, 8, NBL, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_ipm_grid8<T, NBL, NS>;
+    static bool big_lds_enabled = false;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(64), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTG(NBL, NS) template int launch_ipm_grid8<QPX_TU_REAL, NBL, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
+QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) QPX_INSTG(8, 2) QPX_INSTG(13, 2)
 #endif
 
 #if QPX_TU_KERNEL >= 1 && QPX_TU_KERNEL <= 3

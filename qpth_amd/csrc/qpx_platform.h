@@ -108,6 +108,9 @@ QPX_DEV float rcp_(float x)
 }
 QPX_DEV double rcp_(double x)
 {
+#ifdef QPX_EXACT_RCP
+    return 1.0 / x;
+#endif
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
     r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);

@@ -141,6 +141,15 @@ template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, siz
     }
     return QPX_OK;
 }
+template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + 64);
+        T* base = reinterpret_cast<T*>(lds.data());
+        run_block(64, [&](const Block& b) { ipm_grid_body<T, 8, NBL, NS>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
 template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
