@@ -226,11 +226,44 @@ QPX_DEV void grid_solve_neg(const Block& blk, const GridPos<GS>& g, const T (&E)
     GridPos<GS>::sync(blk);
 }
 
+
+// The register-resident matrix operations of the PDIPM loop as a policy, so that the loop body
+// (ipm_loop_body) is written once for every register layout (thread grid here, MFMA tiles in
+// qpx_tile.h).  MP = padded order, NT = threads per QP, scratch = LDS elements the operations use.
+template <class T, int GS, int NBL> struct GridMat {
+    static constexpr int NT = GS * GS, MP = GS * NBL;
+    using Pos = GridPos<GS>;
+    struct Regs { T e[gtri(NBL)]; };
+    QPX_LAYOUT_HD static size_t scratch_elems() { return 2 * (size_t)MP + 4 + (size_t)NBL * GS * GS; }
+    static QPX_DEV void sync(const Block& blk) { GridPos<GS>::sync(blk); }
+    static QPX_DEV const T* image(const T* F, const FacLayout& lay) { return F + (GS == 8 ? lay.Rw : lay.Rg); }
+    static QPX_DEV void load(const Block& blk, const Pos&, Regs& E, const T* img) { grid_load<T, GS, NBL>(blk, E.e, img); }
+    static QPX_DEV void symv(const Block& blk, const Pos& g, const Regs& E, const T* vin, T* vout, T* scratch)
+    {
+        grid_symv<T, GS, NBL>(blk, g, E.e, vin, vout, scratch + 2 * MP + 4);
+    }
+    static QPX_DEV void add_diag(const Pos& g, Regs& E, const T* vd) { grid_add_diag<T, GS, NBL>(g, E.e, vd); }
+    static QPX_DEV bool ldl_inv(const Block& blk, const Pos& g, Regs& E, T* scratch, T* rd, int m)
+    {
+        return grid_ldl_inv<T, GS, NBL>(blk, g, E.e, scratch, scratch + 2 * MP, rd, m);
+    }
+    static QPX_DEV void solve_neg(const Block& blk, const Pos& g, const Regs& E, const T* rd, int m, const T* vin,
+                                  T* vout, T* tmp, T* scratch)
+    {
+        grid_solve_neg<T, GS, NBL>(blk, g, E.e, rd, m, vin, vout, tmp, scratch + 2 * MP + 4);
+    }
+};
+
+// LDS elements of the loop kernel: 12 vectors of v = align4(max(n, MP, q)), 8 control words, scratch
+QPX_LAYOUT_HD size_t lds_elems_ipm_loop(size_t mp, size_t scratch, int n, int q)
+{
+    const size_t v = align4(max2(max2((size_t)n, mp), (size_t)q));
+    return 12 * v + 8 + scratch;
+}
 QPX_LAYOUT_HD size_t lds_elems_ipm_grid(int gs, int nbl, int n, int q)
 {
     const size_t mg = (size_t)gs * nbl;
-    const size_t v = align4(max2(max2((size_t)n, mg), (size_t)q));
-    return 12 * v + 2 * mg + 8 + (size_t)nbl * gs * gs;
+    return lds_elems_ipm_loop(mg, 2 * mg + 4 + (size_t)nbl * gs * gs, n, q);
 }
 
 // out[c] (op)= sum_r Mat[r][c] * vec[r]   -- thread per column c: the loads of a row are
@@ -396,6 +429,8 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
     // ---- scatter the blocks of the swept matrix to the blob
     for (size_t e = blk.tid; e < grid_elems(16, lay.nbg); e += NT) F[lay.Rg + e] = T(0);
     for (size_t e = blk.tid; e < grid_elems(8, lay.nbw); e += NT) F[lay.Rw + e] = T(0);
+    if (lay.nbt > 0)
+        for (size_t e = blk.tid; e < (size_t)tile_nw(lay.nbt) * tile_nslot(lay.nbt) * 256; e += NT) F[lay.Rm + e] = T(0);
     GridPos<GS>::sync(blk);
 #pragma unroll
     for (int li = 0; li < NBL; ++li)
@@ -432,6 +467,10 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
                         wp[wa + 8 * wb] = -val;
                         if (w2i == w2j && zi != zj) wp[wb + 8 * wa] = -val;
                     }
+                    if (lay.nbt > 0) {                                           // and of the matrix-core tiles
+                        F[lay.Rm + tile_image_index(lay.nbt, zi, zj)] = -val;
+                        if (l2i == l2j && zi != zj) F[lay.Rm + tile_image_index(lay.nbt, zj, zi)] = -val;
+                    }
                 }
             }
         }
@@ -443,15 +482,15 @@ QPX_LAYOUT_HD size_t lds_elems_sweep(int nbl) { return (size_t)3 * 16 * nbl + 8 
 // ------------------------------------------------------------------------------------------
 // The PDIPM loop on the format-3 blob.  Mathematics and control flow: see ipm_body (same
 // reference citations); the factorisation is ldl_inv and every solve is two triangular mat-vecs.
-template <class T, int GS, int NBL, int NS>
-QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
+template <class T, class Mat, int NS>
+QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
 {
-    constexpr int M8 = GS * NBL, NT = GS * GS;
-    const GridPos<GS> g(b);
+    constexpr int M8 = Mat::MP, NT = Mat::NT;
+    const typename Mat::Pos g(b);
     const int n = a.n, m = a.m, q = a.q;
     const FacLayout lay = fac_layout(n, m, q);
     T* F = a.fac + (size_t)qp * a.fac_stride;
-    const T* Rg = F + (GS == 8 ? lay.Rw : lay.Rg);
+    const T* Rg = Mat::image(F, lay);
     const size_t v = align4(max2(max2((size_t)n, (size_t)M8), (size_t)q));
     T* rd = lds;          // 1/d_k (M8)
     T* vA = rd + v;       // z' (M8)
@@ -465,10 +504,8 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     T* vX = vRH + v;      // its solution
     T* vTm = vX + v;      // scratch of the solve
     T* vP = vTm + v;      // p / b staging (n)
-    T* vec2 = vP + v;     // 2*M8
-    T* dsl = vec2 + 2 * M8;
-    int* ctrl = reinterpret_cast<int*>(dsl + 4);
-    T* red = dsl + 8;     // NBL*GS*GS
+    int* ctrl = reinterpret_cast<int*>(vP + v);     // 8 elements of control words
+    T* scr = vP + v + 8;  // Mat::scratch_elems()
 
     const int lane = b.lane();
     const bool w0 = b.wave() == 0;
@@ -500,22 +537,22 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         vA[i] = T(1);                     // first use: R 1
         vRH[i] = T(0);
     }
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     block_matTvec<T, 1>(b, vC, F + lay.MT, vP, n, m);
     if (q > 0) {
-        GridPos<GS>::sync(b);
+        Mat::sync(b);
         for (int i = b.tid; i < q; i += NT) vTm[i] = bg[i];
-        GridPos<GS>::sync(b);
+        Mat::sync(b);
         for (int j = b.tid; j < m; j += NT) {
             T acc = vC[j];
             for (int r = 0; r < q; ++r) acc = fma_(-F[lay.W + (size_t)j * q + r], vTm[r], acc);
             vC[j] = acc;
         }
     }
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     QPX_PROF(0)
 
-    T E[gtri(NBL)];
+    typename Mat::Regs E;
     T z[NS], s[NS];
     T tau = 1, btau = 1, sigz = 0, sigs = 0, bres = Lim<T>::inf();
     const T g1n = F[lay.scal];
@@ -525,11 +562,11 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     for (int k = 0; k < NS; ++k) z[k] = s[k] = T(1);
 
     // ---- R 1, then the start point: T = R + I, z_i = -T^-1 c, s_i = -z_i, shifts (batch.py:61-87)
-    grid_load<T, GS, NBL>(b, E, Rg);
-    grid_symv<T, GS, NBL>(b, g, E, vA, vR1, red);
-    grid_add_diag<T, GS, NBL>(g, E, vD);
-    bool ok = grid_ldl_inv<T, GS, NBL>(b, g, E, vec2, dsl, rd, m);
-    if (ok) grid_solve_neg<T, GS, NBL>(b, g, E, rd, m, vC, vX, vTm, red);
+    Mat::load(b, g, E, Rg);
+    Mat::symv(b, g, E, vA, vR1, scr);
+    Mat::add_diag(g, E, vD);
+    bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
+    if (ok) Mat::solve_neg(b, g, E, rd, m, vC, vX, vTm, scr);
     if (w0) {
         if (ok) {
             T x[NS];
@@ -573,14 +610,14 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         }
         if (lane == 0) ctrl[0] = ok ? 0 : 1;
     }
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     int stop = ctrl[0];
     QPX_PROF(1)
 
     for (int it = 0; it < a.maxIter && !stop; ++it) {
-        grid_load<T, GS, NBL>(b, E, Rg);
+        Mat::load(b, g, E, Rg);
         QPX_PROF(2)
-        grid_symv<T, GS, NBL>(b, g, E, vA, vB, red);
+        Mat::symv(b, g, E, vA, vB, scr);
         QPX_PROF(3)
         T mu = 0, feas = 0, resid = 0, szdot = 0;
         if (w0) {
@@ -608,10 +645,10 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
                 tr[0] = pri; tr[1] = dual; tr[2] = mu;
             }
         }
-        GridPos<GS>::sync(b);
-        grid_add_diag<T, GS, NBL>(g, E, vD);
+        Mat::sync(b);
+        Mat::add_diag(g, E, vD);
         QPX_PROF(4)
-        ok = grid_ldl_inv<T, GS, NBL>(b, g, E, vec2, dsl, rd, m);
+        ok = Mat::ldl_inv(b, g, E, scr, rd, m);
         QPX_PROF(5)
         if (w0) {
             int stopf = 0;
@@ -641,11 +678,11 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
             }
             if (lane == 0) ctrl[0] = stopf;
         }
-        GridPos<GS>::sync(b);
+        Mat::sync(b);
         stop = ctrl[0];
         if (stop) break;
         // affine scaling direction: dz_aff = -T^-1 (c + R z)
-        grid_solve_neg<T, GS, NBL>(b, g, E, rd, m, vRH, vX, vTm, red);
+        Mat::solve_neg(b, g, E, rd, m, vRH, vX, vTm, scr);
         T dza[NS], dsa[NS], rs[NS];
         if (w0) {
             ld_slots<NS>(b, dza, vX, m, T(0));
@@ -674,8 +711,8 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
                 if (i < m) vRH[i] = rs[k] * s[k] / z[k];
             }
         }
-        GridPos<GS>::sync(b);
-        grid_solve_neg<T, GS, NBL>(b, g, E, rd, m, vRH, vX, vTm, red);
+        Mat::sync(b);
+        Mat::solve_neg(b, g, E, rd, m, vRH, vX, vTm, scr);
         if (w0) {
             T dz[NS], ds[NS];
             ld_slots<NS>(b, dz, vX, m, T(0));
@@ -703,7 +740,7 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
                 }
             }
         }
-        GridPos<GS>::sync(b);
+        Mat::sync(b);
         QPX_PROF(6)
     }
 
@@ -725,16 +762,16 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     }
     if (q > 0)
         for (int i = b.tid; i < q; i += NT) vTm[i] = bg[i];
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     // zhat = x0 - M^T z' = -K p + N b - M^T z'
     block_matTvec<T, 0>(b, vX, F + lay.Kneg, vP, n, n);
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     block_matTvec<T, 2>(b, vX, F + lay.M, vA, m, n);
     if (q > 0) {
-        GridPos<GS>::sync(b);
+        Mat::sync(b);
         block_matTvec<T, 2>(b, vX, F + lay.NTn, vTm, q, n);
     }
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     for (int i = b.tid; i < n; i += NT) a.zhat[(size_t)qp * n + i] = vX[i];
     if (q > 0) {
         // nu = -S11^-1 b + NTn p - W^T z'
@@ -748,6 +785,12 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     }
     QPX_PROF(7)
     QPX_PROF_DUMP(a.trace ? a.trace + (size_t)qp * 8 : (T*)nullptr, T)
+}
+
+template <class T, int GS, int NBL, int NS>
+QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
+{
+    ipm_loop_body<T, GridMat<T, GS, NBL>, NS>(b, a, qp, lds);
 }
 
 // ------------------------------------------------------------------------------------------

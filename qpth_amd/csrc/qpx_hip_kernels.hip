@@ -6,7 +6,7 @@
 //
 // Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm (workgroup per QP),
 // 3 = kkt/backward, 4 = ipm (wave per QP), 5 = sweep pre-factorisation (16x16 thread grid),
-// 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave).
+// 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only).
 #include <hip/hip_runtime.h>
 
 #include "../../include/qpx.h"
@@ -180,6 +180,29 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
 }
 #define QPX_INSTG(NBL, NS) template int launch_ipm_grid8<QPX_TU_REAL, NBL, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) QPX_INSTG(8, 2) QPX_INSTG(13, 2)
+#elif QPX_TU_KERNEL == 9
+// two workgroups per CU at every instantiated size: <= 256 registers (VGPR + AGPR) per lane
+template <int NBL, int NS> __global__ __launch_bounds__(64 * ((NBL + 1) / 2), 2) void k_ipm_tile(IpmArgs<double> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    ipm_tile_body<NBL, NS>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+}
+template <int NBL, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_ipm_tile<NBL, NS>;
+    static bool big_lds_enabled = false;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * ((NBL + 1) / 2)), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTT(NBL, NS) template int launch_ipm_tile<NBL, NS>(const IpmArgs<double>&, size_t, void*);
+#ifdef QPX_TILE_ONLY_72
+QPX_INSTT(7, 2)
+#else
+QPX_INSTT(1, 1) QPX_INSTT(1, 2) QPX_INSTT(1, 4) QPX_INSTT(2, 1) QPX_INSTT(2, 2) QPX_INSTT(2, 4)
+QPX_INSTT(4, 1) QPX_INSTT(4, 2) QPX_INSTT(4, 4) QPX_INSTT(7, 2) QPX_INSTT(7, 4)
+#endif
 #endif
 
 #if QPX_TU_KERNEL >= 1 && QPX_TU_KERNEL <= 3

@@ -62,6 +62,48 @@ QPX_LAYOUT_HD int grid_nb(int ord)
     return 0;
 }
 
+// ---- matrix-core tile kernels (qpx_tile.h): 16x16 tiles of the lower block triangle, dealt to
+// tile_nw(nbl) waves so that each owns tile_nslot(nbl) of them: wave w has tile row A = nbl-1-w in
+// slots 0..A (slot = tile column) and, if it exists, tile row B in slots NSLOT-1-J.
+QPX_LAYOUT_HD int tile_nb(int m)      // tile rows the kernels are instantiated with for order m (0: n/a)
+{
+    const int need = (m + 15) / 16;
+    if (need <= 1) return 1;
+    if (need <= 2) return 2;
+    if (need <= 4) return 4;
+    if (need <= 7) return 7;
+    return 0;
+}
+QPX_LAYOUT_HD int tile_nw(int nbl) { return (nbl + 1) / 2; }           // waves per QP
+QPX_LAYOUT_HD int tile_nslot(int nbl) { return nbl | 1; }              // tiles per wave
+QPX_LAYOUT_HD int tile_row_a(int nbl, int w) { return nbl - 1 - w; }
+QPX_LAYOUT_HD int tile_row_b(int nbl, int w)
+{
+    const int b = (nbl & 1) ? w - 1 : w;
+    return (b >= 0 && b < nbl - 1 - w) ? b : -1;
+}
+// home of tile (I, J), J <= I
+QPX_LAYOUT_HD void tile_home(int nbl, int I, int J, int* w, int* s)
+{
+    const int wa = nbl - 1 - I;
+    if (wa < tile_nw(nbl)) {
+        *w = wa;
+        *s = J;
+    } else {
+        *w = (nbl & 1) ? I + 1 : I;
+        *s = tile_nslot(nbl) - 1 - J;
+    }
+}
+// image of a symmetric matrix in tile layout: [((w * NSLOT + s) * 4 + r) * 64 + lane]
+QPX_LAYOUT_HD size_t tile_image_index(int nbl, int i, int j)   // i >= j or same diagonal tile
+{
+    int w, s;
+    tile_home(nbl, i >> 4, j >> 4, &w, &s);
+    const int ri = i & 15, c = j & 15;
+    return ((size_t)(w * tile_nslot(nbl) + s) * 4 + (ri >> 2)) * 64 + (size_t)((ri & 3) * 16 + c);
+}
+
+
 struct FacLayout {
     size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, Rw;
     // "format 3" (grid kernels: sweep pre-factorisation, no triangular factors), present when
@@ -69,10 +111,14 @@ struct FacLayout {
     // NTn = -N^T = -(A K')... (q x n), W = G N (m x q), S11i = (A Q^-1 A^T)^-1 (q x q),
     // Rg = R in the 16x16 grid register layout (gtri(nbg) * 256)
     size_t Kneg, M, MT, NTn, W, S11i, Rg;
+    // Rm = R in the tile-register layout of qpx_tile.h (tile_nw * tile_nslot * 256 elements;
+    // entry tile_image_index(nbt, i, j)), present when format 3 is and tile_nb(m) > 0
+    size_t Rm;
     size_t total;
     int nbw;      // wave kernel blocks of 8 for m (0 = n/a)
     int nbg;      // grid blocks of 16 for m
     int nba;      // grid blocks of 16 for the augmented order n+q+m (0 = format 3 unavailable)
+    int nbt;      // tile rows of 16 for m in the matrix-core kernels (0 = n/a)
 };
 
 QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
@@ -104,6 +150,9 @@ QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
         f.S11i = o; o += align4((size_t)q * q);
         f.Rg = o;   o += (size_t)(f.nbg * (f.nbg + 1) / 2) * 256;
     }
+    f.nbt = f.nba > 0 ? tile_nb(m) : 0;
+    f.Rm = o;
+    if (f.nbt > 0) o += (size_t)tile_nw(f.nbt) * tile_nslot(f.nbt) * 256;
     f.total = o;
     return f;
 }

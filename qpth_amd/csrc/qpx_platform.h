@@ -24,6 +24,9 @@ struct Block {
     QPX_DEV int lane() const { return tid & (kWave - 1); }
     QPX_DEV int wave() const { return tid >> 6; }
     QPX_DEV int nwaves() const { return nt >> 6; }
+    // a value every lane of the wave holds, moved to a scalar register so that branches on it are
+    // scalar branches (the compiler cannot see that tid >> 6 is wave-uniform)
+    QPX_DEV int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
 
     // workgroup barrier; LDS and global writes of the workgroup made before it are visible after.
     // The explicit wait is load-bearing: hipcc (ROCm 7.2) dropped the `s_waitcnt lgkmcnt(0)`
@@ -63,6 +66,35 @@ struct Block {
         return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
     }
     QPX_DEV int bcast(int v, int src) const { return __builtin_amdgcn_readlane(v, src); }
+
+    // value of `v` held by lane (lane ^ MASK), MASK in {1, 2, 7, 15}: partners inside a row of 16
+    // lanes, done with DPP moves (quad_perm / row_half_mirror / row_mirror) -- no LDS, ~3 VALU
+    // issues for a double.  The four masks in sequence sum a value over the 16 lanes of a row.
+    template <int MASK> QPX_DEV double xor16(double v) const
+    {
+        static_assert(MASK == 1 || MASK == 2 || MASK == 7 || MASK == 15, "DPP row pattern");
+        constexpr int ctrl = MASK == 1 ? 0xB1 : (MASK == 2 ? 0x4E : (MASK == 7 ? 0x141 : 0x140));
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), ctrl, 0xF, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, 0xF, 0xF, false);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    template <int MASK> QPX_DEV float xor16(float v) const
+    {
+        static_assert(MASK == 1 || MASK == 2 || MASK == 7 || MASK == 15, "DPP row pattern");
+        constexpr int ctrl = MASK == 1 ? 0xB1 : (MASK == 2 ? 0x4E : (MASK == 7 ? 0x141 : 0x140));
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false));
+    }
+
+    // c += A B on the matrix core, A 16x4, B 4x16, one wave (v_mfma_f64_16x16x4_f64).  Lane l gives
+    // a = A[l & 15][l >> 4], b = B[l >> 4][l & 15] and holds c[r] = C[(l >> 4) + 4 r][l & 15].
+    QPX_DEV void mfma16x16x4(double a, double b, double (&c)[4]) const
+    {
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 acc = {c[0], c[1], c[2], c[3]};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        c[0] = acc[0]; c[1] = acc[1]; c[2] = acc[2]; c[3] = acc[3];
+    }
 };
 
 // Rows of 64 consecutive elements of a wave-uniform global array, read as one coalesced

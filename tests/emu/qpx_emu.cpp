@@ -15,6 +15,7 @@
 #include "qpx_kernels.h"
 #include "qpx_wave.h"
 #include "qpx_grid.h"
+#include "qpx_tile.h"
 
 namespace qpx {
 
@@ -60,6 +61,8 @@ template <class Body> static void run_block(int nt, const Body& body)
     sh.wave_bar = wb.data();
     std::vector<unsigned long long> xchg(nt, 0);
     sh.xchg = xchg.data();
+    std::vector<unsigned long long> xchg2(nt, 0);
+    sh.xchg2 = xchg2.data();
     std::vector<ThreadCtx<Body>> ctx(nt);
     std::vector<pthread_t> th(nt);
     pthread_attr_t attr;
@@ -147,6 +150,15 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
         std::vector<unsigned char> lds(lds_bytes + 64);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(64, [&](const Block& b) { ipm_grid_body<T, 8, NBL, NS>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
+template <int NBL, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + 64);
+        double* base = reinterpret_cast<double*>(lds.data());
+        run_block(64 * ((NBL + 1) / 2), [&](const Block& b) { ipm_tile_body<NBL, NS>(b, a, qp, base); });
     }
     return QPX_OK;
 }

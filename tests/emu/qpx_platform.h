@@ -26,6 +26,7 @@ struct EmuShared {
     pthread_barrier_t block_bar;   // all threads of the workgroup
     pthread_barrier_t* wave_bar;   // one per wave
     unsigned long long* xchg;      // one 8-byte exchange slot per thread
+    unsigned long long* xchg2;     // a second one (the B operand of the emulated MFMA)
 };
 
 struct Block {
@@ -36,6 +37,7 @@ struct Block {
     int lane() const { return tid & (kWave - 1); }
     int wave() const { return tid >> 6; }
     int nwaves() const { return nt >> 6; }
+    int uniform(int v) const { return v; }
     void sync() const { pthread_barrier_wait(&sh->block_bar); }
     void wave_sync() const { pthread_barrier_wait(&sh->wave_bar[wave()]); }
 
@@ -57,6 +59,33 @@ struct Block {
     float bcast(float v, int src) const { return exchange(v, src); }
     double bcast(double v, int src) const { return exchange(v, src); }
     int bcast(int v, int src) const { return exchange(v, src); }
+    template <int MASK> double xor16(double v) const { return exchange(v, lane() ^ MASK); }
+    template <int MASK> float xor16(float v) const { return exchange(v, lane() ^ MASK); }
+
+    // c += A B, A 16x4, B 4x16 (see the HIP header for the lane mapping); products are summed in
+    // k order with fused multiply-adds -- the hardware's internal order is not documented, so GPU
+    // and emulation agree to rounding, not bit for bit, once this is used
+    void mfma16x16x4(double a, double b, double (&c)[4]) const
+    {
+        unsigned long long ba, bb;
+        std::memcpy(&ba, &a, 8);
+        std::memcpy(&bb, &b, 8);
+        sh->xchg[tid] = ba;
+        sh->xchg2[tid] = bb;
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        const int base = tid & ~(kWave - 1), g = lane() >> 4, cc = lane() & 15;
+        for (int r = 0; r < 4; ++r) {
+            double acc = c[r];
+            for (int k = 0; k < 4; ++k) {
+                double av, bv;
+                std::memcpy(&av, &sh->xchg[base + (k << 4) + (g + 4 * r)], 8);
+                std::memcpy(&bv, &sh->xchg2[base + (k << 4) + cc], 8);
+                acc = std::fma(av, bv, acc);
+            }
+            c[r] = acc;
+        }
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+    }
 };
 
 template <class T> struct GlobalRows {
