@@ -86,8 +86,9 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * whenever nz+neq+nineq <= 208, else one 256-thread workgroup per QP with the matrices in LDS
  * (or in HBM when they do not fit); 1 = always the workgroup kernels; 2 = workgroup
  * pre-factorisation/backward + the one-wave-per-QP loop (nineq <= 104, nz <= 128).
- * Adding 256 / 512 forces the 16x16-thread (four waves per QP) / 8x8-thread (one wave per QP) form of the
- * grid loop kernel; by default the library picks by batch size.
+ * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
+ * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
+ * at 1 / 2 / 4; by default the library picks by dtype, size and batch.
  * The knob must not change between qpx_pre_factor and the calls that consume its factors.
  * Returns the previous value. */
 int qpx_set_ipm_variant(int variant);

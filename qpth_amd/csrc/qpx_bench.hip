@@ -170,6 +170,56 @@ template <int NB, int MODE> __global__ __launch_bounds__(64) void k_ldl(double* 
     }
 }
 
+// 10. v_mfma_f64_16x16x4_f64: NACC independent accumulators issued round-robin (throughput at
+// NACC = 8, dependent-chain latency at NACC = 1); and the same rank-4 update of a 16x16 tile done
+// with 16 vector FMAs per lane (operands in registers) for comparison
+typedef double d4_t __attribute__((ext_vector_type(4)));
+template <int NACC> __global__ __launch_bounds__(64) void k_mfma_f64(double* out, const double* in, int reps)
+{
+    d4_t acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = d4_t{in[threadIdx.x], in[threadIdx.x + 64], 0.0, 1.0};
+    const double a = in[threadIdx.x + 128] * 1e-3, bb = in[threadIdx.x + 192] * 1e-3;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[i], 0, 0, 0);
+    }
+    double sum = 0;
+    for (int i = 0; i < NACC; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = sum;
+    if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (4.0 * NACC * reps);
+}
+template <int NACC> __global__ __launch_bounds__(64) void k_vfma_tile(double* out, const double* in, int reps)
+{
+    double acc[NACC][4];
+    for (int i = 0; i < NACC; ++i)
+        for (int r = 0; r < 4; ++r) acc[i][r] = in[threadIdx.x + 64 * r];
+    double l[4][4], v[4];
+    for (int r = 0; r < 4; ++r) {
+        v[r] = in[threadIdx.x + 256 + r] * 1e-3;
+        for (int k = 0; k < 4; ++k) l[r][k] = in[threadIdx.x + 300 + 4 * r + k] * 1e-3;
+    }
+    long long t0 = clock64();
+    for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[i][r] = __builtin_fma(l[r][k], v[k], acc[i][r]);
+    }
+    double sum = 0;
+    for (int i = 0; i < NACC; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = sum;
+    if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (4.0 * NACC * reps);
+}
+
 // accuracy of rcp_ against IEEE division over many magnitudes
 __global__ void k_rcp_err(double* out, const double* in, int reps)
 {
@@ -198,6 +248,10 @@ extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, co
     case 6: hipLaunchKernelGGL(k_rcp_lat, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 9: hipLaunchKernelGGL(k_rcp_err, dim3(1), dim3(64), 0, s, out, in, reps); break;
     case 7: hipLaunchKernelGGL(k_bpermute, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 20: hipLaunchKernelGGL(k_mfma_f64<8>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 21: hipLaunchKernelGGL(k_mfma_f64<1>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 22: hipLaunchKernelGGL(k_mfma_f64<2>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 23: hipLaunchKernelGGL(k_vfma_tile<8>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 13: {
         auto k = k_ldl<13, 1>;
         const size_t lds = ((104 * 105) / 2 + 8 + 104 + 8) * 8;

@@ -430,7 +430,7 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
     for (size_t e = blk.tid; e < grid_elems(16, lay.nbg); e += NT) F[lay.Rg + e] = T(0);
     for (size_t e = blk.tid; e < grid_elems(8, lay.nbw); e += NT) F[lay.Rw + e] = T(0);
     if (lay.nbt > 0)
-        for (size_t e = blk.tid; e < (size_t)tile_nw(lay.nbt) * tile_nslot(lay.nbt) * 256; e += NT) F[lay.Rm + e] = T(0);
+        for (size_t e = blk.tid; e < tile_image_elems(lay.nbt); e += NT) F[lay.Rm + e] = T(0);
     GridPos<GS>::sync(blk);
 #pragma unroll
     for (int li = 0; li < NBL; ++li)
@@ -468,8 +468,8 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
                         if (w2i == w2j && zi != zj) wp[wb + 8 * wa] = -val;
                     }
                     if (lay.nbt > 0) {                                           // and of the matrix-core tiles
-                        F[lay.Rm + tile_image_index(lay.nbt, zi, zj)] = -val;
-                        if (l2i == l2j && zi != zj) F[lay.Rm + tile_image_index(lay.nbt, zj, zi)] = -val;
+                        F[lay.Rm + tile_image_index(zi, zj)] = -val;
+                        if (l2i == l2j && zi != zj) F[lay.Rm + tile_image_index(zj, zi)] = -val;
                     }
                 }
             }
@@ -561,66 +561,19 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
 #pragma unroll
     for (int k = 0; k < NS; ++k) z[k] = s[k] = T(1);
 
-    // ---- R 1, then the start point: T = R + I, z_i = -T^-1 c, s_i = -z_i, shifts (batch.py:61-87)
-    Mat::load(b, g, E, Rg);
-    Mat::symv(b, g, E, vA, vR1, scr);
-    Mat::add_diag(g, E, vD);
-    bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
-    if (ok) Mat::solve_neg(b, g, E, rd, m, vC, vX, vTm, scr);
-    if (w0) {
-        if (ok) {
-            T x[NS];
-            ld_slots<NS>(b, x, vX, m, T(0));
-            T mnz = Lim<T>::inf(), mns = Lim<T>::inf();
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                if (i < m) {
-                    mnz = (x[k] < mnz) ? x[k] : mnz;
-                    mns = (-x[k] < mns) ? -x[k] : mns;
-                }
-            }
-            mnz = wave_min(b, mnz);
-            mns = wave_min(b, mns);
-            sigz = (mnz < T(0)) ? (T(1) - mnz) : T(0);
-            sigs = (mns < T(0)) ? (T(1) - mns) : T(0);
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                if (i < m) {
-                    z[k] = x[k] + sigz;
-                    s[k] = -x[k] + sigs;
-                    vA[i] = x[k];
-                    vBZ[i] = z[k];
-                    vBS[i] = s[k];
-                }
-            }
-        } else {
-            st |= QPX_ST_KKT_BREAKDOWN;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                if (i < m) { vBZ[i] = T(1); vBS[i] = T(1); }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int i = k * kWave + lane;
-            if (i >= m && i < M8) vA[i] = T(0);
-        }
-        if (lane == 0) ctrl[0] = ok ? 0 : 1;
-    }
-    Mat::sync(b);
-    int stop = ctrl[0];
-    QPX_PROF(1)
-
-    for (int it = 0; it < a.maxIter && !stop; ++it) {
+    // ---- pass -1 is the start point: T = R + I, z_i = -T^-1 c, s_i = -z_i, shifts (batch.py:61-87),
+    // and R 1 on the way; passes 0.. are the IPM iterations.  One loop so that the factorisation and
+    // the solves are instantiated once (they are the bulk of the kernel's code).
+    bool ok = true;
+    int stop = 0;
+    for (int it = -1; it < a.maxIter && !stop; ++it) {
+        const bool first = it < 0;
         Mat::load(b, g, E, Rg);
         QPX_PROF(2)
-        Mat::symv(b, g, E, vA, vB, scr);
+        Mat::symv(b, g, E, vA, first ? vR1 : vB, scr);       // first pass: vA = 1
         QPX_PROF(3)
         T mu = 0, feas = 0, resid = 0, szdot = 0;
-        if (w0) {
+        if (w0 && !first) {
             T pri2 = 0;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
@@ -655,7 +608,15 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
             if (!ok) {
                 st |= QPX_ST_KKT_BREAKDOWN;
                 stopf = 1;
-            } else {
+                if (first) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const int i = k * kWave + lane;
+                        if (i < m) { vBZ[i] = T(1); vBS[i] = T(1); }
+                        if (i < M8) vA[i] = T(0);
+                    }
+                }
+            } else if (!first) {
                 iters = it + 1;
                 const bool better = (it == 0) || (resid < bres);
                 if (better) {
@@ -681,8 +642,43 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         Mat::sync(b);
         stop = ctrl[0];
         if (stop) break;
-        // affine scaling direction: dz_aff = -T^-1 (c + R z)
-        Mat::solve_neg(b, g, E, rd, m, vRH, vX, vTm, scr);
+        // first pass: z_i = -T^-1 c; iterations: affine scaling direction dz_aff = -T^-1 (c + R z)
+        Mat::solve_neg(b, g, E, rd, m, first ? vC : vRH, vX, vTm, scr);
+        if (first) {
+            if (w0) {
+                T x[NS];
+                ld_slots<NS>(b, x, vX, m, T(0));
+                T mnz = Lim<T>::inf(), mns = Lim<T>::inf();
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int i = k * kWave + lane;
+                    if (i < m) {
+                        mnz = (x[k] < mnz) ? x[k] : mnz;
+                        mns = (-x[k] < mns) ? -x[k] : mns;
+                    }
+                }
+                mnz = wave_min(b, mnz);
+                mns = wave_min(b, mns);
+                sigz = (mnz < T(0)) ? (T(1) - mnz) : T(0);
+                sigs = (mns < T(0)) ? (T(1) - mns) : T(0);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int i = k * kWave + lane;
+                    if (i < m) {
+                        z[k] = x[k] + sigz;
+                        s[k] = -x[k] + sigs;
+                        vA[i] = x[k];
+                        vBZ[i] = z[k];
+                        vBS[i] = s[k];
+                    } else if (i < M8) {
+                        vA[i] = T(0);
+                    }
+                }
+            }
+            Mat::sync(b);
+            QPX_PROF(1)
+            continue;
+        }
         T dza[NS], dsa[NS], rs[NS];
         if (w0) {
             ld_slots<NS>(b, dza, vX, m, T(0));

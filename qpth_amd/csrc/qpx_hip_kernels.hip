@@ -181,27 +181,40 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
 #define QPX_INSTG(NBL, NS) template int launch_ipm_grid8<QPX_TU_REAL, NBL, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) QPX_INSTG(8, 2) QPX_INSTG(13, 2)
 #elif QPX_TU_KERNEL == 9
-// two workgroups per CU at every instantiated size: <= 256 registers (VGPR + AGPR) per lane
-template <int NBL, int NS> __global__ __launch_bounds__(64 * ((NBL + 1) / 2), 2) void k_ipm_tile(IpmArgs<double> a)
+// NW waves per QP.  Two waves per SIMD (<= 256 registers per lane) except for the one-wave form at
+// the largest size, whose 28 tiles alone are 224 registers.
+template <int NBL, int NW, int NS>
+__global__ __launch_bounds__(64 * NW, (NW <= 2 && NBL > 4) ? 1 : 2) void k_ipm_tile(IpmArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    ipm_tile_body<NBL, NS>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+    ipm_tile_body<NBL, NW, NS>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
-template <int NBL, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
+template <int NBL, int NW, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
 {
-    auto kern = k_ipm_tile<NBL, NS>;
+    auto kern = k_ipm_tile<NBL, NW, NS>;
     static bool big_lds_enabled = false;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * ((NBL + 1) / 2)), lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NW), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
-#define QPX_INSTT(NBL, NS) template int launch_ipm_tile<NBL, NS>(const IpmArgs<double>&, size_t, void*);
-#ifdef QPX_TILE_ONLY_72
-QPX_INSTT(7, 2)
+#ifdef QPX_PANEL_PROF
+// profiling build only: read and reset the panel sub-phase counters (see qpx_tile.h)
+extern "C" int qpx_panel_prof_read(unsigned long long* out)
+{
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qpx_panel_prof), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(qpx_panel_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+#define QPX_INSTT(NBL, NW, NS) template int launch_ipm_tile<NBL, NW, NS>(const IpmArgs<double>&, size_t, void*);
+#ifdef QPX_TILE_ONLY
+QPX_INSTT(7, QPX_TILE_ONLY, 2)
 #else
-QPX_INSTT(1, 1) QPX_INSTT(1, 2) QPX_INSTT(1, 4) QPX_INSTT(2, 1) QPX_INSTT(2, 2) QPX_INSTT(2, 4)
-QPX_INSTT(4, 1) QPX_INSTT(4, 2) QPX_INSTT(4, 4) QPX_INSTT(7, 2) QPX_INSTT(7, 4)
+QPX_INSTT(1, 1, 1) QPX_INSTT(1, 1, 2) QPX_INSTT(1, 1, 4) QPX_INSTT(2, 1, 1) QPX_INSTT(2, 1, 2) QPX_INSTT(2, 1, 4)
+QPX_INSTT(4, 1, 1) QPX_INSTT(4, 1, 2) QPX_INSTT(4, 1, 4) QPX_INSTT(4, 2, 1) QPX_INSTT(4, 2, 2) QPX_INSTT(4, 2, 4)
+QPX_INSTT(7, 1, 2) QPX_INSTT(7, 1, 4) QPX_INSTT(7, 2, 2) QPX_INSTT(7, 2, 4) QPX_INSTT(7, 4, 2) QPX_INSTT(7, 4, 4)
 #endif
 #endif
 

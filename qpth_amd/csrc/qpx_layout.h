@@ -62,9 +62,9 @@ QPX_LAYOUT_HD int grid_nb(int ord)
     return 0;
 }
 
-// ---- matrix-core tile kernels (qpx_tile.h): 16x16 tiles of the lower block triangle, dealt to
-// tile_nw(nbl) waves so that each owns tile_nslot(nbl) of them: wave w has tile row A = nbl-1-w in
-// slots 0..A (slot = tile column) and, if it exists, tile row B in slots NSLOT-1-J.
+// ---- matrix-core tile kernels (qpx_tile.h): R as 16x16 tiles of the lower block triangle, each
+// in the register layout of the f64 MFMA accumulator: element (i, j), tile (I, J) = (i/16, j/16),
+// J <= I, is entry (I (I+1)/2 + J) * 256 + ((i%16) / 4) * 64 + ((i%16) % 4) * 16 + j%16.
 QPX_LAYOUT_HD int tile_nb(int m)      // tile rows the kernels are instantiated with for order m (0: n/a)
 {
     const int need = (m + 15) / 16;
@@ -74,35 +74,12 @@ QPX_LAYOUT_HD int tile_nb(int m)      // tile rows the kernels are instantiated 
     if (need <= 7) return 7;
     return 0;
 }
-QPX_LAYOUT_HD int tile_nw(int nbl) { return (nbl + 1) / 2; }           // waves per QP
-QPX_LAYOUT_HD int tile_nslot(int nbl) { return nbl | 1; }              // tiles per wave
-QPX_LAYOUT_HD int tile_row_a(int nbl, int w) { return nbl - 1 - w; }
-QPX_LAYOUT_HD int tile_row_b(int nbl, int w)
+QPX_LAYOUT_HD size_t tile_image_elems(int nbl) { return (size_t)(nbl * (nbl + 1) / 2) * 256; }
+QPX_LAYOUT_HD size_t tile_image_index(int i, int j)   // i >= j, or both in the same diagonal tile
 {
-    const int b = (nbl & 1) ? w - 1 : w;
-    return (b >= 0 && b < nbl - 1 - w) ? b : -1;
+    const int I = i >> 4, J = j >> 4, ri = i & 15, c = j & 15;
+    return ((size_t)(I * (I + 1) / 2 + J) * 4 + (ri >> 2)) * 64 + (size_t)((ri & 3) * 16 + c);
 }
-// home of tile (I, J), J <= I
-QPX_LAYOUT_HD void tile_home(int nbl, int I, int J, int* w, int* s)
-{
-    const int wa = nbl - 1 - I;
-    if (wa < tile_nw(nbl)) {
-        *w = wa;
-        *s = J;
-    } else {
-        *w = (nbl & 1) ? I + 1 : I;
-        *s = tile_nslot(nbl) - 1 - J;
-    }
-}
-// image of a symmetric matrix in tile layout: [((w * NSLOT + s) * 4 + r) * 64 + lane]
-QPX_LAYOUT_HD size_t tile_image_index(int nbl, int i, int j)   // i >= j or same diagonal tile
-{
-    int w, s;
-    tile_home(nbl, i >> 4, j >> 4, &w, &s);
-    const int ri = i & 15, c = j & 15;
-    return ((size_t)(w * tile_nslot(nbl) + s) * 4 + (ri >> 2)) * 64 + (size_t)((ri & 3) * 16 + c);
-}
-
 
 struct FacLayout {
     size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, Rw;
@@ -111,8 +88,8 @@ struct FacLayout {
     // NTn = -N^T = -(A K')... (q x n), W = G N (m x q), S11i = (A Q^-1 A^T)^-1 (q x q),
     // Rg = R in the 16x16 grid register layout (gtri(nbg) * 256)
     size_t Kneg, M, MT, NTn, W, S11i, Rg;
-    // Rm = R in the tile-register layout of qpx_tile.h (tile_nw * tile_nslot * 256 elements;
-    // entry tile_image_index(nbt, i, j)), present when format 3 is and tile_nb(m) > 0
+    // Rm = R in the tile-register layout of qpx_tile.h (tile_image_elems(nbt) elements, entry
+    // tile_image_index(i, j)), present when format 3 is and tile_nb(m) > 0
     size_t Rm;
     size_t total;
     int nbw;      // wave kernel blocks of 8 for m (0 = n/a)
@@ -152,7 +129,7 @@ QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
     }
     f.nbt = f.nba > 0 ? tile_nb(m) : 0;
     f.Rm = o;
-    if (f.nbt > 0) o += (size_t)tile_nw(f.nbt) * tile_nslot(f.nbt) * 256;
+    if (f.nbt > 0) o += tile_image_elems(f.nbt);
     f.total = o;
     return f;
 }

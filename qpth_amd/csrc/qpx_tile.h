@@ -26,38 +26,64 @@
 //   update    one v_mfma_f64_16x16x4 per owned tile below the panel: E += (-l~) b.
 //
 // That is 1 matrix instruction per tile and 4 columns where the thread-grid kernel issues
-// 4 x 28 vector FMAs per thread, and the ~60 instructions of per-column bookkeeping are paid once
-// per four columns.  Tile rows are dealt to waves in pairs (I, NBL-1-I or so) so that every wave
-// owns NBL (or NBL+1) tiles: tile (I, J) sits in slot J of the wave that has I as its "row A" and
-// in slot NSLOT-1-J of the wave that has it as its "row B" -- all register indices are static once
-// the panel index is a template parameter, ownership tests are wave-uniform branches.
+// 4 x 28 vector FMAs per thread, and the per-column bookkeeping is paid once per four columns.
+//
+// NW waves share a QP (NW = 1, 2 or 4).  Tile rows are dealt round-robin from the bottom: wave w
+// owns rows I_p = NBL-1 - p NW - (w or NW-1-w, alternating), p = 0 .. NPOS-1 ("positions"), and keeps tile (I_p, J) in
+// register slot pbase(p) + J -- a static index for static (p, J); which row a position is, is a
+// wave-uniform scalar (a compile-time constant when NW = 1).  The tile row Ip of the current
+// panel is a run-time value (the panel code exists 4 times -- once per register index SP --
+// not 4 NBL times), tests against it are scalar branches.
 //
 // The triangular mat-vecs of the solve (x = -W~^T D^-1 W~ r) and the symmetric mat-vec R z use
-// vector FMAs on the same registers; sums along a tile row are DPP butterflies inside 16-lane
-// rows (no LDS), sums down a column go through LDS partials in a fixed order (deterministic).
+// vector FMAs on the same registers; sums along tile rows and down tile columns go through LDS
+// partials that are added in a fixed order (deterministic results).
 #pragma once
 #include "qpx_grid.h"
 
+// Sub-phase timers of one panel (-DQPX_PANEL_PROF, scripts/prof_panel.py): thread 0 of every QP adds the
+// shader-clock cycles of publish / barrier / pivot block / operands / update to qpx_panel_prof[].
+#ifdef QPX_PANEL_PROF
+static __device__ unsigned long long qpx_panel_prof[8];   // one copy per translation unit; TU 9 reads its own
+#define QPX_PP(i)                                                        \
+    {                                                                    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      \
+        const long long qpx_pp_n = clock64();                            \
+        pacc[i] += qpx_pp_n - pacc[7];                                   \
+        pacc[7] = qpx_pp_n;                                              \
+    }
+#else
+#define QPX_PP(i)
+#endif
+
 namespace qpx {
 
-struct TilePos {
-    int tid, lane, w, g, c, A, B;   // B = -1: no second tile row
-    QPX_DEV TilePos(const Block& blk, int nbl)
-        : tid(blk.tid), lane(blk.lane()), w(blk.uniform(blk.wave())), g(blk.lane() >> 4), c(blk.lane() & 15),
-          A(tile_row_a(nbl, blk.uniform(blk.wave()))), B(tile_row_b(nbl, blk.uniform(blk.wave())))
-    {
-    }
-};
-
-template <int NBL> struct TileMat {
+template <int NBL, int NW> struct TileMat {
     using T = double;
-    static constexpr int NW = (NBL + 1) / 2, NT = 64 * NW, NSLOT = NBL | 1, MP = 16 * NBL;
-    struct Pos : TilePos {
-        QPX_DEV explicit Pos(const Block& blk) : TilePos(blk, NBL) {}
+    static constexpr int NPOS = (NBL + NW - 1) / NW, NT = 64 * NW, MP = 16 * NBL;
+    static constexpr int psize(int p) { return NBL - p * NW; }            // tiles of position p (wave 0: the longest)
+    static constexpr int pbase(int p)
+    {
+        int b = 0;
+        for (int k = 0; k < p; ++k) b += psize(k);
+        return b;
+    }
+    static constexpr int NSLOT = pbase(NPOS);
+    static constexpr int NROW = 16 * NPOS;                                 // matrix rows a wave owns (at most)
+    struct Pos {
+        int tid, lane, w, g, c;
+        QPX_DEV explicit Pos(const Block& blk)
+            : tid(blk.tid), lane(blk.lane()), w(NW == 1 ? 0 : blk.uniform(blk.wave())), g(blk.lane() >> 4),
+              c(blk.lane() & 15)
+        {
+        }
+        // tile row of position p (< 0: none).  Rows are dealt from the bottom in snake order (w, then
+        // NW-1-w, ...) so that the tile counts of the waves stay close as the factorisation retires rows
+        QPX_DEV int row(int p) const { return NBL - 1 - p * NW - ((p & 1) ? NW - 1 - w : w); }
     };
     struct Regs { T e[NSLOT][4]; };
-    // scratch: X (2 x 4 x MP) | S (2 x 16) | part (NW x NBL x 64) | yrow (MP)
-    static constexpr int kX = 0, kS = 8 * MP, kPart = 8 * MP + 32, kRow = kPart + NW * NBL * 64;
+    // scratch: X (2 x 4 x MP) | S (2 x 16) | part (NW x NBL x 64) | red (NW x NROW x 17) | yrow (MP)
+    static constexpr int kX = 0, kS = 8 * MP, kPart = kS + 32, kRed = kPart + NW * NBL * 64, kRow = kRed + NW * NROW * 17;
     QPX_LAYOUT_HD static size_t scratch_elems() { return (size_t)kRow + MP; }
     static QPX_DEV void sync(const Block& blk)
     {
@@ -66,51 +92,74 @@ template <int NBL> struct TileMat {
     }
     static QPX_DEV const T* image(const T* F, const FacLayout& lay) { return F + lay.Rm; }
 
+    // img: tile (I, J), J <= I, at [(I (I + 1) / 2 + J) * 256 + r * 64 + lane]
     static QPX_DEV void load(const Block& blk, const Pos& p, Regs& E, const T* img)
     {
-        const GlobalRows<T> rows(img, NW * NSLOT * 256, p.lane);
+        const GlobalRows<T> rows(img, NBL * (NBL + 1) / 2 * 256, p.lane);
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s)
+        for (int pp = 0; pp < NPOS; ++pp) {
+            const int I = p.row(pp);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) E.e[s][r] = rows.row((p.w * NSLOT + s) * 4 + r);
+            for (int J = 0; J < psize(pp); ++J) {
+                if (J <= I) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) E.e[pbase(pp) + J][r] = rows.row((I * (I + 1) / 2 + J) * 4 + r);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) E.e[pbase(pp) + J][r] = T(0);
+                }
+            }
+        }
     }
 
     static QPX_DEV void add_diag(const Pos& p, Regs& E, const T* vd)
     {
 #pragma unroll
-        for (int J = 0; J < NBL; ++J) {
-            if (J == p.A) {
+        for (int pp = 0; pp < NPOS; ++pp) {
+            const int I = p.row(pp);
+#pragma unroll
+            for (int J = 0; J < psize(pp); ++J) {
+                if (J != I) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (p.c == p.g + 4 * r) E.e[J][r] += vd[16 * J + p.c];
-            }
-            if (J == p.B) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (p.c == p.g + 4 * r) E.e[NSLOT - 1 - J][r] += vd[16 * J + p.c];
+                    if (p.c == p.g + 4 * r) E.e[pbase(pp) + J][r] += vd[16 * J + p.c];
             }
         }
     }
 
-    // sum over the 16 lanes of a DPP row; every lane ends with the total
-    static QPX_DEV T rowsum16(const Block& blk, T v)
+    // Sums over the 16 columns of every tile row of this wave: acc[pp][r] of lane (g, c) is a partial of
+    // matrix row 16 I_pp + g + 4 r.  Through LDS: one padded line of 17 per row, one lane adds a line.
+    template <class F>
+    static QPX_DEV void row_reduce(const Block& blk, const Pos& p, const T (&acc)[NPOS][4], T* scr, F&& emit)
     {
-        v += blk.template xor16<1>(v);
-        v += blk.template xor16<2>(v);
-        v += blk.template xor16<7>(v);
-        v += blk.template xor16<15>(v);
-        return v;
+        T* red = scr + kRed + p.w * (NROW * 17);
+#pragma unroll
+        for (int pp = 0; pp < NPOS; ++pp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((pp * 4 + r) * 4 + p.g) * 17 + p.c] = acc[pp][r];
+        blk.wave_sync();
+#pragma unroll
+        for (int o0 = 0; o0 < NROW; o0 += 64) {
+            const int o = o0 + p.lane;                       // o = (pp * 4 + r) * 4 + g
+            if (o < NROW) {
+                const T* q = red + o * 17;
+                const T s = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
+                            (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+                const int I = p.row(o >> 4);
+                if (I >= 0) emit(16 * I + (o & 3) + 4 * ((o >> 2) & 3), s);
+            }
+        }
     }
 
-    // out[j] = base[j] (if any) + the column partials of every wave that owns a tile in column j/16
+    // out[j] = +-(base[j] + the column partials of every wave), fixed order
     template <bool kNeg>
     static QPX_DEV void gather_cols(const Block& blk, const T* part, const T* base, T* out)
     {
         for (int j = blk.tid; j < MP; j += NT) {
             const int J = j >> 4, cc = j & 15;
             T sum = base[j];
+#pragma unroll
             for (int w = 0; w < NW; ++w) {
-                if (tile_row_a(NBL, w) < J) continue;
                 const T* pp = part + (size_t)(w * NBL + J) * 64 + cc;
                 sum += (pp[0] + pp[16]) + (pp[32] + pp[48]);
             }
@@ -123,110 +172,89 @@ template <int NBL> struct TileMat {
     {
         T* part = scr + kPart;
         T* yrow = scr + kRow;
-        T accA[4] = {0, 0, 0, 0}, accB[4] = {0, 0, 0, 0}, uA[4], uB[4];
+        T acc[NPOS][4], u[NPOS][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uA[r] = vin[16 * p.A + p.g + 4 * r];
-            uB[r] = p.B >= 0 ? vin[16 * p.B + p.g + 4 * r] : T(0);
+        for (int pp = 0; pp < NPOS; ++pp) {
+            const int I = p.row(pp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[pp][r] = T(0);
+                u[pp][r] = I >= 0 ? vin[16 * I + p.g + 4 * r] : T(0);
+            }
         }
 #pragma unroll
         for (int J = 0; J < NBL; ++J) {
-            if (J > p.A) continue;
             const T xj = vin[16 * J + p.c];
             T col = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) accA[r] = fma_(E.e[J][r], xj, accA[r]);
-            if (J < p.A) {
+            for (int pp = 0; pp < NPOS; ++pp) {
+                if (J >= psize(pp)) continue;
+                const int I = p.row(pp);
+                if (J > I) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) col = fma_(E.e[J][r], uA[r], col);
-            }
-            if (J <= p.B) {
+                for (int r = 0; r < 4; ++r) acc[pp][r] = fma_(E.e[pbase(pp) + J][r], xj, acc[pp][r]);
+                if (J < I) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) accB[r] = fma_(E.e[NSLOT - 1 - J][r], xj, accB[r]);
-                if (J < p.B) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) col = fma_(E.e[NSLOT - 1 - J][r], uB[r], col);
+                    for (int r = 0; r < 4; ++r) col = fma_(E.e[pbase(pp) + J][r], u[pp][r], col);
                 }
             }
             part[(size_t)(p.w * NBL + J) * 64 + p.lane] = col;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            accA[r] = rowsum16(blk, accA[r]);
-            if (NBL > 1) accB[r] = rowsum16(blk, accB[r]);
-        }
-        if (p.c == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                yrow[16 * p.A + p.g + 4 * r] = accA[r];
-                if (p.B >= 0) yrow[16 * p.B + p.g + 4 * r] = accB[r];
-            }
-        }
+        row_reduce(blk, p, acc, scr, [&](int i, T s) { yrow[i] = s; });
         sync(blk);
         gather_cols<false>(blk, part, yrow, vout);
         sync(blk);
     }
 
-    // ---- one panel of ldl_inv: rows/columns k0 .. k0+3, k0 = 16 Ip + 4 SP.  The tile row Ip is a
-    // run-time (wave-uniform) value so that the code exists four times, not 4 NBL times; the register
-    // index SP inside a tile is static.  gm[k] = (g == k) as 0/1.
+    // ---- one panel of ldl_inv: rows/columns k0 .. k0+3, k0 = 16 Ip + 4 SP.  gm[k] = (g == k) as 0/1.
     template <int SP>
-    static QPX_DEV bool panel(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, const T (&gm)[4])
+    static QPX_DEV bool panel(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, const T (&gm)[4],
+                              long long (&pacc)[8])
     {
+        QPX_PP(5)
         const int k0 = 16 * Ip + 4 * SP;
         T* X = scr + kX + (SP & 1) * 4 * MP;
         T* S = scr + kS + (SP & 1) * 16;
         const bool inpan = (p.c >> 2) == SP;
         const int kc = p.c & 3;
-        const bool ownA = p.A == Ip, ownB = p.B == Ip;
         // -- publish: the panel's four rows left of the panel ...
-        if (ownA || ownB) {
 #pragma unroll
-            for (int J = 0; J < NBL; ++J)
-                if (J <= Ip) X[p.g * MP + 16 * J + p.c] = ownA ? E.e[J][SP] : E.e[NSLOT - 1 - J][SP];
+        for (int pp = 0; pp < NPOS; ++pp) {
+            if (p.row(pp) != Ip) continue;
+#pragma unroll
+            for (int J = 0; J < psize(pp); ++J)
+                if (J <= Ip) X[p.g * MP + 16 * J + p.c] = E.e[pbase(pp) + J][SP];
         }
         // ... the pivot block (identity in X, the block itself in S) and the four columns below it.
         // Row g + 4 r of tile row I lies below the panel iff I > Ip or r > SP.  The panel's own columns
         // restart from zero: they are published, and the update writes -l~ W into them.
+        if (inpan) {
 #pragma unroll
-        for (int J = 0; J < NBL; ++J) {
-            if (J != Ip) continue;
-            if (inpan) {
-                if (ownA || ownB) {
-                    S[p.g * 4 + kc] = ownA ? E.e[J][SP] : E.e[NSLOT - 1 - J][SP];
-                    X[p.g * MP + 16 * J + p.c] = (kc == p.g) ? T(1) : T(0);
-                }
-                if (p.A >= Ip) {
+            for (int J = 0; J < NBL; ++J) {
+                if (J != Ip) continue;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (p.A > Ip || r > SP) X[kc * MP + 16 * p.A + p.g + 4 * r] = E.e[J][r];
-                        E.e[J][r] = T(0);
+                for (int pp = 0; pp < NPOS; ++pp) {
+                    if (J >= psize(pp)) continue;
+                    const int I = p.row(pp);
+                    if (I < Ip) continue;
+                    if (I == Ip) {
+                        S[p.g * 4 + kc] = E.e[pbase(pp) + J][SP];
+                        X[p.g * MP + 16 * J + p.c] = (kc == p.g) ? T(1) : T(0);
                     }
-                }
-                if (p.B >= Ip) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (p.B > Ip || r > SP) X[kc * MP + 16 * p.B + p.g + 4 * r] = E.e[NSLOT - 1 - J][r];
-                        E.e[NSLOT - 1 - J][r] = T(0);
+                        if (I > Ip || r > SP) X[kc * MP + 16 * I + p.g + 4 * r] = E.e[pbase(pp) + J][r];
+                        E.e[pbase(pp) + J][r] = T(0);
                     }
                 }
             }
         }
+        QPX_PP(0)
         sync(blk);
+        QPX_PP(1)
         // -- the 4 x 4 pivot block: S = L D L^T, W = L^-1 (unit lower), every lane the same numbers
         const T s00 = S[0], s10 = S[4], s11 = S[5], s20 = S[8], s21 = S[9], s22 = S[10];
         const T s30 = S[12], s31 = S[13], s32 = S[14], s33 = S[15];
-        // operand reads that do not depend on the factorisation are issued before it
-        const T* Xg = X + p.g * MP;
-        T x0[NBL], x1[NBL], x2[NBL], xg[NBL];
-#pragma unroll
-        for (int J = 0; J < NBL; ++J) {
-            const int j = 16 * J + p.c;
-            x0[J] = X[j];
-            x1[J] = X[MP + j];
-            x2[J] = X[2 * MP + j];
-            xg[J] = Xg[j];
-        }
         const T d0 = s00, r0 = rcp_(d0);
         const T l10 = s10 * r0, l20 = s20 * r0, l30 = s30 * r0;
         const T d1 = fma_(-l10, s10, s11), r1 = rcp_(d1);
@@ -251,40 +279,46 @@ template <int NBL> struct TileMat {
         const T rg = fma_(gm[3], r3, fma_(gm[2], r2, fma_(gm[1], r1, gm[0] * r0)));
         const T dg = fma_(gm[3], d3, fma_(gm[2], d2, fma_(gm[1], d1, gm[0] * d0)));
         if (p.w == 0 && p.c == 0) rd[k0 + p.g] = rg;
-        // -- operands
+        QPX_PP(2)
+        // -- operands: bop[J] is the B operand of tile column J; the A operand of tile row I is
+        // -bop[I] / d_g, with zeros for the rows that are not below the panel
+        const T* Xg = X + p.g * MP;
         T bop[NBL];
-        T tA = 0, tB = 0;
 #pragma unroll
         for (int J = 0; J < NBL; ++J) {
-            bop[J] = fma_(cg2, x2[J], fma_(cg1, x1[J], fma_(cg0, x0[J], xg[J])));
-            if (J == p.A) tA = bop[J];
-            if (J == p.B) tB = bop[J];
+            const int j = 16 * J + p.c;
+            bop[J] = fma_(cg2, X[2 * MP + j], fma_(cg1, X[MP + j], fma_(cg0, X[j], Xg[j])));
         }
-        const bool right = p.c > 4 * SP + 3;          // rows of the panel's tile row below the panel
-        const T aA = (p.A > Ip || (ownA && right)) ? -(tA * rg) : T(0);
-        const T aB = (p.B > Ip || (ownB && right)) ? -(tB * rg) : T(0);
+        const bool right = p.c > 4 * SP + 3;
+        T aop[NPOS];
+#pragma unroll
+        for (int pp = 0; pp < NPOS; ++pp) {
+            const int I = p.row(pp);
+            T t = 0;
+#pragma unroll
+            for (int J = 0; J < psize(pp); ++J)
+                if (J == I) t = bop[J];
+            aop[pp] = (I > Ip || (I == Ip && right)) ? -(t * rg) : T(0);
+        }
+        QPX_PP(3)
         // -- the panel's own rows are final
-        if (ownA) {
 #pragma unroll
-            for (int J = 0; J < NBL; ++J)
-                if (J <= Ip) E.e[J][SP] = (J == Ip && inpan && kc == p.g) ? dg : bop[J];
-        }
-        if (ownB) {
+        for (int pp = 0; pp < NPOS; ++pp) {
+            if (p.row(pp) != Ip) continue;
 #pragma unroll
-            for (int J = 0; J < NBL; ++J)
-                if (J <= Ip) E.e[NSLOT - 1 - J][SP] = (J == Ip && inpan && kc == p.g) ? dg : bop[J];
+            for (int J = 0; J < psize(pp); ++J)
+                if (J <= Ip) E.e[pbase(pp) + J][SP] = (J == Ip && inpan && kc == p.g) ? dg : bop[J];
         }
         // -- rank-4 update of every owned tile at or below the panel's tile row
-        if (p.A >= Ip) {
 #pragma unroll
-            for (int J = 0; J < NBL; ++J)
-                if (J <= p.A) blk.mfma16x16x4(aA, bop[J], E.e[J]);
-        }
-        if (p.B >= Ip) {
+        for (int pp = 0; pp < NPOS; ++pp) {
+            const int I = p.row(pp);
+            if (I < Ip) continue;
 #pragma unroll
-            for (int J = 0; J < NBL; ++J)
-                if (J <= p.B) blk.mfma16x16x4(aB, bop[J], E.e[NSLOT - 1 - J]);
+            for (int J = 0; J < psize(pp); ++J)
+                if (J <= I) blk.mfma16x16x4(aop[pp], bop[J], E.e[pbase(pp) + J]);
         }
+        QPX_PP(4)
         return true;
     }
 
@@ -294,15 +328,25 @@ template <int NBL> struct TileMat {
     {
         const T gm[4] = {p.g == 0 ? T(1) : T(0), p.g == 1 ? T(1) : T(0), p.g == 2 ? T(1) : T(0), p.g == 3 ? T(1) : T(0)};
         bool ok = true;
+        long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef QPX_PANEL_PROF
+        pacc[7] = clock64();
+#endif
 #pragma unroll 1
         for (int Ip = 0; Ip < NBL && ok; ++Ip) {
             const int k0 = 16 * Ip;
             if (k0 >= m) break;
-            ok = panel<0>(blk, p, E, scr, rd, Ip, gm);
-            if (ok && k0 + 4 < m) ok = panel<1>(blk, p, E, scr, rd, Ip, gm);
-            if (ok && k0 + 8 < m) ok = panel<2>(blk, p, E, scr, rd, Ip, gm);
-            if (ok && k0 + 12 < m) ok = panel<3>(blk, p, E, scr, rd, Ip, gm);
+            ok = panel<0>(blk, p, E, scr, rd, Ip, gm, pacc);
+            if (ok && k0 + 4 < m) ok = panel<1>(blk, p, E, scr, rd, Ip, gm, pacc);
+            if (ok && k0 + 8 < m) ok = panel<2>(blk, p, E, scr, rd, Ip, gm, pacc);
+            if (ok && k0 + 12 < m) ok = panel<3>(blk, p, E, scr, rd, Ip, gm, pacc);
         }
+#ifdef QPX_PANEL_PROF
+        if (p.tid == 0) {
+            for (int i = 0; i < 6; ++i) atomicAdd(&qpx_panel_prof[i], (unsigned long long)pacc[i]);
+            atomicAdd(&qpx_panel_prof[6], 1ull);
+        }
+#endif
         sync(blk);
         return ok;
     }
@@ -313,62 +357,48 @@ template <int NBL> struct TileMat {
     {
         T* part = scr + kPart;
         // u = D^-1 W~ vin: sums along tile rows, complete inside the owning wave
-        T accA[4] = {0, 0, 0, 0}, accB[4] = {0, 0, 0, 0};
+        T acc[NPOS][4];
+#pragma unroll
+        for (int pp = 0; pp < NPOS; ++pp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[pp][r] = T(0);
 #pragma unroll
         for (int J = 0; J < NBL; ++J) {
-            if (J > p.A) continue;
             const T xj = vin[16 * J + p.c];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const T e = (J < p.A || p.c < p.g + 4 * r) ? E.e[J][r] : T(0);
-                accA[r] = fma_(e, xj, accA[r]);
-            }
-            if (J <= p.B) {
+            for (int pp = 0; pp < NPOS; ++pp) {
+                if (J >= psize(pp)) continue;
+                const int I = p.row(pp);
+                if (J > I) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const T e = (J < p.B || p.c < p.g + 4 * r) ? E.e[NSLOT - 1 - J][r] : T(0);
-                    accB[r] = fma_(e, xj, accB[r]);
+                    const T e = (J < I || p.c < p.g + 4 * r) ? E.e[pbase(pp) + J][r] : T(0);
+                    acc[pp][r] = fma_(e, xj, acc[pp][r]);
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            accA[r] = rowsum16(blk, accA[r]);
-            if (NBL > 1) accB[r] = rowsum16(blk, accB[r]);
-        }
-        if (p.c == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ia = 16 * p.A + p.g + 4 * r;
-                tmp[ia] = (ia < m) ? (accA[r] + vin[ia]) * rd[ia] : T(0);
-                if (p.B >= 0) {
-                    const int ib = 16 * p.B + p.g + 4 * r;
-                    tmp[ib] = (ib < m) ? (accB[r] + vin[ib]) * rd[ib] : T(0);
-                }
-            }
-        }
+        row_reduce(blk, p, acc, scr, [&](int i, T s) { tmp[i] = (i < m) ? (s + vin[i]) * rd[i] : T(0); });
         sync(blk);
         // x = W~^T u: sums down columns, partial per wave, gathered in a fixed order
-        T uA[4], uB[4];
+        T u[NPOS][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uA[r] = tmp[16 * p.A + p.g + 4 * r];
-            uB[r] = p.B >= 0 ? tmp[16 * p.B + p.g + 4 * r] : T(0);
+        for (int pp = 0; pp < NPOS; ++pp) {
+            const int I = p.row(pp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[pp][r] = I >= 0 ? tmp[16 * I + p.g + 4 * r] : T(0);
         }
 #pragma unroll
         for (int J = 0; J < NBL; ++J) {
-            if (J > p.A) continue;
             T col = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const T e = (J < p.A || p.c < p.g + 4 * r) ? E.e[J][r] : T(0);
-                col = fma_(e, uA[r], col);
-            }
-            if (J <= p.B) {
+            for (int pp = 0; pp < NPOS; ++pp) {
+                if (J >= psize(pp)) continue;
+                const int I = p.row(pp);
+                if (J > I) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const T e = (J < p.B || p.c < p.g + 4 * r) ? E.e[NSLOT - 1 - J][r] : T(0);
-                    col = fma_(e, uB[r], col);
+                    const T e = (J < I || p.c < p.g + 4 * r) ? E.e[pbase(pp) + J][r] : T(0);
+                    col = fma_(e, u[pp][r], col);
                 }
             }
             part[(size_t)(p.w * NBL + J) * 64 + p.lane] = col;
@@ -379,16 +409,16 @@ template <int NBL> struct TileMat {
     }
 };
 
-QPX_LAYOUT_HD size_t lds_elems_ipm_tile(int nbl, int n, int q)
+QPX_LAYOUT_HD size_t lds_elems_ipm_tile(int nbl, int nw, int n, int q)
 {
-    const size_t mp = 16 * (size_t)nbl, nw = (size_t)tile_nw(nbl);
-    return lds_elems_ipm_loop(mp, 8 * mp + 32 + nw * nbl * 64 + mp, n, q);
+    const size_t mp = 16 * (size_t)nbl, npos = (size_t)(nbl + nw - 1) / nw;
+    return lds_elems_ipm_loop(mp, 8 * mp + 32 + (size_t)nw * nbl * 64 + (size_t)nw * 16 * npos * 17 + mp, n, q);
 }
 
-template <int NBL, int NS>
+template <int NBL, int NW, int NS>
 QPX_DEV void ipm_tile_body(const Block& b, const IpmArgs<double>& a, int qp, double* lds)
 {
-    ipm_loop_body<double, TileMat<NBL>, NS>(b, a, qp, lds);
+    ipm_loop_body<double, TileMat<NBL, NW>, NS>(b, a, qp, lds);
 }
 
 }  // namespace qpx

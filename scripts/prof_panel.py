@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Sub-phase breakdown of one panel of the tile kernel's blocked LDL^T (libqpx_hip_pprof.so,
+`make -C qpth_amd/csrc panelprof`): shader-clock ticks thread 0 of each QP spent in publish /
+barrier / pivot block / operands / update, per factorisation and per panel.  The timers force
+`s_waitcnt 0` at every cut, so overlap across cuts is lost -- read the split, not the sum."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import problems  # noqa: E402
+from qpth_amd import _lib  # noqa: E402
+from qpth_amd.kkt import KKTFactors  # noqa: E402
+
+NAMES = ["publish", "barrier", "S read + 4x4 + masks", "operands (LDS + fma)", "assign + mfma issue", "entry (mfma drain)"]
+
+
+def main():
+    B, n, m, q = [int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (512, 100, 100, 0))]
+    dev = torch.device("cuda:0")
+    lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_pprof.so"))
+    _lib.set_test_backend(lib)
+    lib.dll.qpx_set_ipm_variant(int(os.environ.get("QPX_VARIANT", "0")))
+    arrs = problems.prof_qp(B, n, m, q, 0, np.float64)
+    tQ, tp, tG, th, tA, tb = [torch.tensor(x, device=dev) for x in arrs]
+    fac = KKTFactors.build(tQ, tG, tA, B)
+    out = (ctypes.c_ulonglong * 8)()
+    for rep in range(2):
+        res = fac.ipm(tp, th, tb)
+        torch.cuda.synchronize()
+        lib.dll.qpx_panel_prof_read(out)
+    c = np.array(list(out), dtype=np.float64)
+    nfac = c[6]
+    npan = (m + 3) // 4
+    print("B=%d n=%d m=%d q=%d variant=%s: %d factorisations, %d panels each; ticks per factorisation %.0f" % (
+        B, n, m, q, os.environ.get("QPX_VARIANT", "0"), nfac, npan, c[:6].sum() / nfac))
+    for i, nm in enumerate(NAMES):
+        print("  %-24s %10.0f per factorisation  %8.0f per panel (%5.1f%%)" % (nm, c[i] / nfac, c[i] / nfac / npan, 100 * c[i] / c[:6].sum()))
+
+
+if __name__ == "__main__":
+    main()

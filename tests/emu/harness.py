@@ -26,16 +26,20 @@ def emu_lib():
 
 
 @contextlib.contextmanager
-def emulated(threads=128):
-    """Run qpth_amd on CPU tensors through the emulator inside this block."""
+def emulated(threads=128, variant=0):
+    """Run qpth_amd on CPU tensors through the emulator inside this block.  `variant` is the
+    qpx_set_ipm_variant knob (which kernel family / form runs, see include/qpx.h)."""
     from qpth_amd import _lib
     old = os.environ.get("QPX_EMU_THREADS")
     os.environ["QPX_EMU_THREADS"] = str(threads)
-    _lib.set_test_backend(emu_lib())
+    lib = emu_lib()
+    old_variant = lib.dll.qpx_set_ipm_variant(int(variant))
+    _lib.set_test_backend(lib)
     try:
         yield
     finally:
         _lib.set_test_backend(None)
+        lib.dll.qpx_set_ipm_variant(old_variant)
         if old is None:
             os.environ.pop("QPX_EMU_THREADS", None)
         else:
