@@ -69,6 +69,7 @@ template <int NBL, int NW> struct TileMat {
         return b;
     }
     static constexpr int NSLOT = pbase(NPOS);
+    static constexpr int minrow(int p) { return NBL - 1 - p * NW - (NW - 1); }   // smallest row any wave has at position p
     static constexpr int NROW = 16 * NPOS;                                 // matrix rows a wave owns (at most)
     struct Pos {
         int tid, lane, w, g, c;
@@ -264,24 +265,25 @@ template <int NBL, int NW> struct TileMat {
         const T v32 = fma_(-l31, v21, fma_(-l30, s20, s32));
         const T l32 = v32 * r2;
         const T d3 = fma_(-l32, v32, fma_(-l31, v31, fma_(-l30, s30, s33))), r3 = rcp_(d3);
-        const bool good = (d0 > T(0)) && (d1 > T(0)) && (d2 > T(0)) && (d3 > T(0)) && finite_(d0) && finite_(d1) &&
-                          finite_(d2) && finite_(d3);
+        const T big = T(1e300);                  // NaN fails d > 0, +inf fails d < big
+        const bool good = (d0 > T(0)) && (d1 > T(0)) && (d2 > T(0)) && (d3 > T(0)) && (d0 < big) && (d1 < big) &&
+                          (d2 < big) && (d3 < big);
         if (!good) return false;
         const T w10 = -l10, w21 = -l21, w32 = -l32;
         const T w20 = fma_(l21, l10, -l20);
         const T w31 = fma_(l32, l21, -l31);
         const T w30 = fma_(-w32, l20, fma_(-w31, l10, -l30));
-        // row g of W, 1/d_g and d_g of this lane's group: sums against the 0/1 group masks (branch-free,
+        // row g of W and 1/d_g of this lane's group: sums against the 0/1 group masks (branch-free,
         // and cheaper than chains of 64-bit selects)
         const T cg0 = fma_(gm[3], w30, fma_(gm[2], w20, gm[1] * w10));
         const T cg1 = fma_(gm[3], w31, gm[2] * w21);
         const T cg2 = gm[3] * w32;
         const T rg = fma_(gm[3], r3, fma_(gm[2], r2, fma_(gm[1], r1, gm[0] * r0)));
-        const T dg = fma_(gm[3], d3, fma_(gm[2], d2, fma_(gm[1], d1, gm[0] * d0)));
         if (p.w == 0 && p.c == 0) rd[k0 + p.g] = rg;
         QPX_PP(2)
-        // -- operands: bop[J] is the B operand of tile column J; the A operand of tile row I is
-        // -bop[I] / d_g, with zeros for the rows that are not below the panel
+        // -- operands: bop[J] is the B operand of tile column J (the new W~ rows of the panel left of it,
+        // L~_pp^-1 inside it, the un-scaled columns right of it); the A operand of tile row I is the same
+        // combination at position 16 I + c, times -1/d_g, with zeros for rows not below the panel
         const T* Xg = X + p.g * MP;
         T bop[NBL];
 #pragma unroll
@@ -289,25 +291,26 @@ template <int NBL, int NW> struct TileMat {
             const int j = 16 * J + p.c;
             bop[J] = fma_(cg2, X[2 * MP + j], fma_(cg1, X[MP + j], fma_(cg0, X[j], Xg[j])));
         }
-        const bool right = p.c > 4 * SP + 3;
+        const T nrg = -rg;
         T aop[NPOS];
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
             const int I = p.row(pp);
-            T t = 0;
-#pragma unroll
-            for (int J = 0; J < psize(pp); ++J)
-                if (J == I) t = bop[J];
-            aop[pp] = (I > Ip || (I == Ip && right)) ? -(t * rg) : T(0);
+            aop[pp] = T(0);
+            if (I < Ip) continue;
+            const int i = 16 * I + p.c;
+            const T t = fma_(cg2, X[2 * MP + i], fma_(cg1, X[MP + i], fma_(cg0, X[i], Xg[i])));
+            aop[pp] = (I > Ip || p.c > 4 * SP + 3) ? t * nrg : T(0);
         }
         QPX_PP(3)
-        // -- the panel's own rows are final
+        // -- the panel's own rows are final: W~ rows left of the panel, L~_pp^-1 inside it.  (The diagonal
+        // entries get the 1 of the unit factor; the d_k live in rd[] as reciprocals, E's diagonal is never
+        // read after the factorisation.  Slots right of the diagonal tile are unused, writing them is free.)
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
             if (p.row(pp) != Ip) continue;
 #pragma unroll
-            for (int J = 0; J < psize(pp); ++J)
-                if (J <= Ip) E.e[pbase(pp) + J][SP] = (J == Ip && inpan && kc == p.g) ? dg : bop[J];
+            for (int J = 0; J < psize(pp); ++J) E.e[pbase(pp) + J][SP] = bop[J];
         }
         // -- rank-4 update of every owned tile at or below the panel's tile row
 #pragma unroll
@@ -316,7 +319,7 @@ template <int NBL, int NW> struct TileMat {
             if (I < Ip) continue;
 #pragma unroll
             for (int J = 0; J < psize(pp); ++J)
-                if (J <= I) blk.mfma16x16x4(aop[pp], bop[J], E.e[pbase(pp) + J]);
+                if (J <= minrow(pp) || J <= I) blk.mfma16x16x4(aop[pp], bop[J], E.e[pbase(pp) + J]);
         }
         QPX_PP(4)
         return true;

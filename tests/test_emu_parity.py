@@ -32,9 +32,9 @@ def tens(arrs, dtype=torch.float64, grad=True):
     return out
 
 
-def run_qpf(arrs, dl, dtype=torch.float64, threads=128, **kw):
+def run_qpf(arrs, dl, dtype=torch.float64, threads=128, variant=0, **kw):
     tq = tens(arrs, dtype)
-    with emulated(threads):
+    with emulated(threads, variant):
         z = QPFunction(verbose=-1, **kw)(*tq)
         z.backward(torch.tensor(dl, dtype=dtype))
     return z.detach().numpy(), [t.grad.numpy() if t.grad is not None else None for t in tq]
@@ -190,3 +190,25 @@ def test_batch_of_one_uses_the_reference_stall_counter():
     with emulated(64):
         z = QPFunction(verbose=-1)(*tq)
     assert rel_err(z.numpy(), g["b1_zhat"][i:i + 1]).max() < TOL
+
+
+# every form of the loop kernel the dispatcher can pick (include/qpx.h, qpx_set_ipm_variant):
+# 1 = workgroup kernels, 2 = wave kernel, +256 / +512 = 16x16 / 8x8 thread grid, +1024 = matrix-core
+# tiles with 1 / 2 / 4 waves per QP (+2048 / +4096 / +8192)
+LOOP_FORMS = [1, 2, 256, 512, 1024 + 2048, 1024 + 4096, 1024 + 8192]
+
+
+@pytest.mark.parametrize("variant", LOOP_FORMS)
+@pytest.mark.parametrize("shape", [(2, 12, 9, 3), (1, 40, 52, 0)])
+def test_every_loop_kernel_form(variant, shape):
+    """The forms differ only in how the per-iteration linear algebra is laid out on the machine: all of
+    them must return the oracle's optimum and gradients."""
+    B, n, m, q = shape
+    arrs = problems.prof_qp(B, n, m, q, seed=11)
+    dl = np.random.RandomState(5).randn(B, n)
+    xr, _, _, _, grads_ref, _ = orc.qp_forward_backward(*arrs, dl, per_qp=True, stall_policy=2)
+    z, grads = run_qpf(arrs, dl, variant=variant)
+    assert rel_err(z, xr).max() < TOL
+    for mine, ref in zip(grads, grads_ref):
+        if ref is not None and mine is not None:
+            assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())

@@ -271,3 +271,30 @@ def test_large_qp_hbm_resident_path(dev):
     x, y, lam, s, info = orc.OracleQP(Q, p, G, h, A, b).forward()
     z, _ = run_qpf([Q, p, G, h, A, b], np.ones((4, 200)), dev)
     assert rel_err(z, x).max() < TOL
+
+
+# ---------------------------------------------------------------- 4. every form of the loop kernel
+# include/qpx.h, qpx_set_ipm_variant: 1 = workgroup kernels, 2 = wave kernel, +256 / +512 = 16x16 / 8x8
+# thread grid, +1024 = matrix-core tiles with 1 / 2 / 4 waves per QP (+2048 / +4096 / +8192)
+LOOP_FORMS = [1, 2, 256, 512, 1024 + 2048, 1024 + 4096, 1024 + 8192]
+
+
+@pytest.mark.parametrize("variant", LOOP_FORMS)
+@pytest.mark.parametrize("shape", [(6, 12, 9, 3), (48, 100, 100, 0), (32, 40, 52, 5)])
+def test_every_loop_kernel_form(dev, variant, shape):
+    """The dispatcher picks one form per (dtype, size, batch); all of them must agree with the oracle."""
+    from oracle import qp_oracle as orc
+    from qpth_amd import _lib
+    B, n, m, q = shape
+    arrs = problems.prof_qp(B, n, m, q, seed=11)
+    dl = np.random.RandomState(5).randn(B, n)
+    xr, _, _, _, grads_ref, _ = orc.qp_forward_backward(*arrs, dl, per_qp=True, stall_policy=2)
+    old = _lib.hip().dll.qpx_set_ipm_variant(variant)
+    try:
+        z, grads = run_qpf(arrs, dl, dev)
+    finally:
+        _lib.hip().dll.qpx_set_ipm_variant(old)
+    assert rel_err(z, xr).max() < TOL
+    for mine, ref in zip(grads, grads_ref):
+        if ref is not None and mine is not None:
+            assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
