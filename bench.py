@@ -36,6 +36,22 @@ from qpth_amd.kkt import KKTFactors, set_stall_policy  # noqa: E402
 from qpth_amd import _lib  # noqa: E402
 
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+# Dense f64 / f32 peaks.  f32: 157.3 TF (MI355X_MICROARCH.md, matrix = vector).  f64: the guide has no
+# row for it; 78.6 TF is AMD's MI355X datasheet number for both the vector and the matrix pipe, and our
+# micro-benchmarks agree: v_fma_f64 issues every 4.07 ticks per wave (77 TF over 1024 SIMDs at the
+# measured 2.39 GHz tick), v_mfma_f64_16x16x4 every 83 ticks (60 TF) -- scripts/ubench_mfma.py.
+MFMA_PEAK = {"f64": 78.6e12, "f32": 157.3e12}
+
+
+def algorithmic_flops_per_qp(n, m, q, passes):
+    """flops the loop kernel's algorithm needs per QP.  `passes` = IPM iterations + 1
+    (the start point is one more factorisation + solve).  Per pass: the factorisation with in-place
+    inverse factor, m^3/3 multiply-adds; two solves of two triangular mat-vecs, 2 m^2; one symmetric
+    mat-vec, m^2.  Once: c = h + M p, zhat = -K p - M^T z' (and the neq terms)."""
+    per_pass = 2.0 * (m ** 3 / 3.0 + 3.0 * m * m)
+    once = 2.0 * (2.0 * m * n + n * n + 2.0 * q * (n + m + q))
+    return passes * per_pass + once
+
 
 
 def algorithmic_bytes_per_qp(n, m, q, w):
@@ -143,7 +159,11 @@ def main():
 
         fwd_r, fwd_w, bwd_r, bwd_w = algorithmic_bytes_per_qp(n, m, q, w)
         ipm_bytes = (fwd_r + fwd_w) * B          # the forward's compulsory traffic, DESIGN.md section 6
-        achieved = ipm_bytes / t_ipm
+        # The loop kernel is compute-side bound (55 flop per compulsory byte at C2, machine balance ~10):
+        # its roofline is the dense matrix/vector peak of the dtype it computes in.
+        ipm_flops = algorithmic_flops_per_qp(n, m, q, iters_mean + 1.0) * B
+        achieved = ipm_flops / t_ipm
+        peak = MFMA_PEAK[args.dtype]
         traffic = None
         tf = os.path.join(ROOT, "profiles", "ipm_traffic.json")
         if os.path.exists(tf):
@@ -153,9 +173,11 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_ipm_grid (PDIPM loop, one launch per forward)", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": ipm_bytes, "launch_ms": t_ipm * 1e3}
+        roofline = {"kernel": "PDIPM loop kernel (k_ipm_tile / k_ipm_grid, one launch per forward)", "bound": "mfma",
+                    "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": traffic, "algorithmic_flops_per_launch": ipm_flops,
+                    "algorithmic_bytes_per_launch": ipm_bytes, "hbm_frac": ipm_bytes / t_ipm / HBM_PEAK,
+                    "launch_ms": t_ipm * 1e3}
 
         cpu_baseline = None
         if not args.no_cpu_baseline:

@@ -45,20 +45,25 @@ template <> struct Lim<double> {
 // ------------------------------------------------------------------------------------------
 // wave-level helpers (every lane of the calling wave takes part)
 
+// Reductions over the 64 lanes; every lane gets the result.  Inside the four 16-lane rows with DPP
+// moves, across the rows with four v_readlane broadcasts: ~25 VALU issues and no LDS traffic (the
+// ds_bpermute butterfly these replace cost ~600 ticks per reduction on MI355X).
 template <class T> QPX_DEV T wave_sum(const Block& b, T v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += b.shfl_xor(v, o);
-    return v;
+    v += b.template xor16<1>(v);
+    v += b.template xor16<2>(v);
+    v += b.template xor16<7>(v);
+    v += b.template xor16<15>(v);
+    return (b.bcast(v, 0) + b.bcast(v, 16)) + (b.bcast(v, 32) + b.bcast(v, 48));
 }
+template <class T> QPX_DEV T min2_(T a, T c) { return (c < a) ? c : a; }
 template <class T> QPX_DEV T wave_min(const Block& b, T v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const T w = b.shfl_xor(v, o);
-        v = (w < v) ? w : v;
-    }
-    return v;
+    v = min2_(v, b.template xor16<1>(v));
+    v = min2_(v, b.template xor16<2>(v));
+    v = min2_(v, b.template xor16<7>(v));
+    v = min2_(v, b.template xor16<15>(v));
+    return min2_(min2_(b.bcast(v, 0), b.bcast(v, 16)), min2_(b.bcast(v, 32), b.bcast(v, 48)));
 }
 
 // A vector of length n is held by ONE wave as NS registers per lane: element i lives in
