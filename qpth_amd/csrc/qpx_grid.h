@@ -254,11 +254,12 @@ template <class T, int GS, int NBL> struct GridMat {
     }
 };
 
-// LDS elements of the loop kernel: 12 vectors of v = align4(max(n, MP, q)), 8 control words, scratch
+// LDS elements of the loop kernel: 19 vectors of v = align4(max(n, MP, q)), 16 scalars + 8 control
+// words, scratch
 QPX_LAYOUT_HD size_t lds_elems_ipm_loop(size_t mp, size_t scratch, int n, int q)
 {
     const size_t v = align4(max2(max2((size_t)n, mp), (size_t)q));
-    return 12 * v + 8 + scratch;
+    return 19 * v + 24 + scratch;
 }
 QPX_LAYOUT_HD size_t lds_elems_ipm_grid(int gs, int nbl, int n, int q)
 {
@@ -427,9 +428,12 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
         return;
     }
     // ---- scatter the blocks of the swept matrix to the blob
-    for (size_t e = blk.tid; e < grid_elems(16, lay.nbg); e += NT) F[lay.Rg + e] = T(0);
-    for (size_t e = blk.tid; e < grid_elems(8, lay.nbw); e += NT) F[lay.Rw + e] = T(0);
-    if (lay.nbt > 0)
+    const bool wRg = (a.images & 1) != 0, wRw = (a.images & 2) != 0 && lay.nbw > 0, wRm = (a.images & 4) != 0 && lay.nbt > 0;
+    if (wRg)
+        for (size_t e = blk.tid; e < grid_elems(16, lay.nbg); e += NT) F[lay.Rg + e] = T(0);
+    if (wRw)
+        for (size_t e = blk.tid; e < grid_elems(8, lay.nbw); e += NT) F[lay.Rw + e] = T(0);
+    if (wRm)
         for (size_t e = blk.tid; e < tile_image_elems(lay.nbt); e += NT) F[lay.Rm + e] = T(0);
     GridPos<GS>::sync(blk);
 #pragma unroll
@@ -458,16 +462,18 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
                 } else {                                                         // R = -block, grid layout of order m
                     const int zj = j - nq;
                     const int l2i = zi >> 4, ai = zi & 15, l2j = zj >> 4, bj = zj & 15;
-                    T* blkp = F + lay.Rg + (size_t)(l2i * (l2i + 1) / 2 + l2j) * 256;
-                    blkp[ai + 16 * bj] = -val;
-                    if (l2i == l2j && zi != zj) blkp[bj + 16 * ai] = -val;
-                    if (lay.nbw > 0) {                                           // and of the 8x8 grid
+                    if (wRg) {
+                        T* blkp = F + lay.Rg + (size_t)(l2i * (l2i + 1) / 2 + l2j) * 256;
+                        blkp[ai + 16 * bj] = -val;
+                        if (l2i == l2j && zi != zj) blkp[bj + 16 * ai] = -val;
+                    }
+                    if (wRw) {                                                   // and of the 8x8 grid
                         const int w2i = zi >> 3, wa = zi & 7, w2j = zj >> 3, wb = zj & 7;
                         T* wp = F + lay.Rw + (size_t)(w2i * (w2i + 1) / 2 + w2j) * 64;
                         wp[wa + 8 * wb] = -val;
                         if (w2i == w2j && zi != zj) wp[wb + 8 * wa] = -val;
                     }
-                    if (lay.nbt > 0) {                                           // and of the matrix-core tiles
+                    if (wRm) {                                                   // and of the matrix-core tiles
                         F[lay.Rm + tile_image_index(zi, zj)] = -val;
                         if (l2i == l2j && zi != zj) F[lay.Rm + tile_image_index(zj, zi)] = -val;
                     }
@@ -504,8 +510,16 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     T* vX = vRH + v;      // its solution
     T* vTm = vX + v;      // scratch of the solve
     T* vP = vTm + v;      // p / b staging (n)
-    int* ctrl = reinterpret_cast<int*>(vP + v);     // 8 elements of control words
-    T* scr = vP + v + 8;  // Mat::scratch_elems()
+    T* vZ = vP + v;       // z, s and their reciprocals
+    T* vS = vZ + v;
+    T* vRZ = vS + v;
+    T* vRS = vRZ + v;
+    T* vDZA = vRS + v;    // affine step, corrector right-hand side rs
+    T* vDSA = vDZA + v;
+    T* vRSC = vDSA + v;
+    T* sc = vRSC + v;                               // 16 scalars of the IPM state
+    int* ctrl = reinterpret_cast<int*>(sc + 16);    // 8 elements of control words
+    T* scr = sc + 24;     // Mat::scratch_elems()
 
     const int lane = b.lane();
     const bool w0 = b.wave() == 0;
@@ -552,19 +566,27 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     Mat::sync(b);
     QPX_PROF(0)
 
+    // The IPM state of wave 0 (z, s, their reciprocals, step directions, scalars) lives in LDS between
+    // the blocks that use it, not in registers: it is touched for a few hundred instructions per
+    // iteration, and carried through the factorisation it cost 32 spilled VGPRs (scratch reloads with
+    // a memory round trip each) -- measured on MI355X.
     typename Mat::Regs E;
-    T z[NS], s[NS];
-    T tau = 1, btau = 1, sigz = 0, sigs = 0, bres = Lim<T>::inf();
-    const T g1n = F[lay.scal];
-    T feas_prev = 0, alpha_prev = 0;
-    int nnot = 0, floor_hit = 0, st = 0, iters = 0;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) z[k] = s[k] = T(1);
+    enum { kTau = 0, kBtau, kSigz, kSigs, kBres, kFeasPrev, kAlphaPrev, kMu, kSzdot, kFeas, kResid };
+    enum { kStop = 0, kNnot, kFloor, kSt, kIters };
+    if (b.tid == 0) {
+        sc[kTau] = T(1); sc[kBtau] = T(1); sc[kSigz] = T(0); sc[kSigs] = T(0); sc[kBres] = Lim<T>::inf();
+        sc[kFeasPrev] = T(0); sc[kAlphaPrev] = T(0);
+        ctrl[kStop] = 0; ctrl[kNnot] = 0; ctrl[kFloor] = 0; ctrl[kSt] = 0; ctrl[kIters] = 0;
+    }
+    for (int i = b.tid; i < M8; i += NT) {
+        vZ[i] = T(1); vS[i] = T(1); vRZ[i] = T(1); vRS[i] = T(1);
+        vDZA[i] = T(0); vDSA[i] = T(0); vRSC[i] = T(0);
+    }
+    Mat::sync(b);
 
     // ---- pass -1 is the start point: T = R + I, z_i = -T^-1 c, s_i = -z_i, shifts (batch.py:61-87),
     // and R 1 on the way; passes 0.. are the IPM iterations.  One loop so that the factorisation and
     // the solves are instantiated once (they are the bulk of the kernel's code).
-    bool ok = true;
     int stop = 0;
     for (int it = -1; it < a.maxIter && !stop; ++it) {
         const bool first = it < 0;
@@ -572,78 +594,90 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         QPX_PROF(2)
         Mat::symv(b, g, E, vA, first ? vR1 : vB, scr);       // first pass: vA = 1
         QPX_PROF(3)
-        T mu = 0, feas = 0, resid = 0, szdot = 0;
         if (w0 && !first) {
-            T pri2 = 0;
+            const T tsz = sc[kTau] * sc[kSigz];
+            T pri2 = 0, szdot = 0;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int i = k * kWave + lane;
                 if (i < m) {
-                    const T rz = s[k] - vC[i] - vB[i];
+                    const T zk = vZ[i], sk = vS[i];
+                    const T rz = sk - vC[i] - vB[i];
                     pri2 = fma_(rz, rz, pri2);
-                    szdot = fma_(s[k], z[k], szdot);
-                    vD[i] = s[k] / z[k];
-                    vRH[i] = vC[i] + vB[i] + tau * sigz * vR1[i];       // affine right-hand side c + R z
+                    szdot = fma_(sk, zk, szdot);
+                    vRH[i] = vC[i] + vB[i] + tsz * vR1[i];       // affine right-hand side c + R z
+                    // 1/z, 1/s and d = s/z once per iteration: every later division by z or s is a multiplication
+                    const T rzk = rcp_(zk);
+                    vRZ[i] = rzk;
+                    vRS[i] = rcp_(sk);
+                    vD[i] = sk * rzk;
                 }
             }
             pri2 = wave_sum(b, pri2);
             szdot = wave_sum(b, szdot);
-            mu = abs_(szdot / mT);
+            const T mu = abs_(szdot / mT);
             const T pri = sqrt_(pri2);
-            const T dual = tau * sigz * g1n;
-            feas = pri + dual;
-            resid = feas + mT * mu;
-            if (a.trace && lane == 0) {
-                T* tr = a.trace + ((size_t)it * a.B + qp) * 3;
-                tr[0] = pri; tr[1] = dual; tr[2] = mu;
+            const T dual = tsz * F[lay.scal];      // || G^T 1 ||
+            if (lane == 0) {
+                sc[kMu] = mu; sc[kSzdot] = szdot; sc[kFeas] = pri + dual; sc[kResid] = pri + dual + mT * mu;
+                if (a.trace) {
+                    T* tr = a.trace + ((size_t)it * a.B + qp) * 3;
+                    tr[0] = pri; tr[1] = dual; tr[2] = mu;
+                }
             }
         }
         Mat::sync(b);
         Mat::add_diag(g, E, vD);
         QPX_PROF(4)
-        ok = Mat::ldl_inv(b, g, E, scr, rd, m);
+        const bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
         QPX_PROF(5)
         if (w0) {
             int stopf = 0;
             if (!ok) {
-                st |= QPX_ST_KKT_BREAKDOWN;
+                if (lane == 0) ctrl[kSt] |= QPX_ST_KKT_BREAKDOWN;
                 stopf = 1;
                 if (first) {
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        const int i = k * kWave + lane;
+                    for (int i = lane; i < M8; i += kWave) {
                         if (i < m) { vBZ[i] = T(1); vBS[i] = T(1); }
-                        if (i < M8) vA[i] = T(0);
+                        vA[i] = T(0);
                     }
                 }
             } else if (!first) {
-                iters = it + 1;
+                const T resid = sc[kResid], feas = sc[kFeas], mu = sc[kMu], tau = sc[kTau];
+                T bres = sc[kBres];
+                int nnot = ctrl[kNnot], floor_hit = ctrl[kFloor];
                 const bool better = (it == 0) || (resid < bres);
                 if (better) {
-                    bres = resid; btau = tau; nnot = 0;
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        const int i = k * kWave + lane;
-                        if (i < m) { vBZ[i] = z[k]; vBS[i] = s[k]; }
-                    }
+                    bres = resid; nnot = 0;
+                    for (int i = lane; i < m; i += kWave) { vBZ[i] = vZ[i]; vBS[i] = vS[i]; }
                 } else if (a.stall_policy == 1 || (a.stall_policy == 2 && mT * mu < feas)) {
                     nnot += 1;
                 } else {
                     nnot = 0;
                 }
-                if (a.stall_policy == 2 && it >= 1 && feas > T(2) * (T(1) - alpha_prev) * feas_prev) floor_hit = 1;
-                feas_prev = feas;
+                if (a.stall_policy == 2 && it >= 1 && feas > T(2) * (T(1) - sc[kAlphaPrev]) * sc[kFeasPrev]) floor_hit = 1;
                 if ((a.stall_policy != 0 && nnot >= a.notImprovedLim) || bres < a.eps || mu > T(1e32)) stopf = 1;
                 if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-4) * feas) stopf = 1;
-                if (!finite_(resid)) { stopf = 1; st |= QPX_ST_NONFINITE; }
+                const bool bad = !finite_(resid);
+                if (bad) stopf = 1;
+                b.wave_sync();       // every lane has read the scalars lane 0 is about to replace
+                if (lane == 0) {
+                    ctrl[kIters] = it + 1;
+                    if (better) { sc[kBres] = bres; sc[kBtau] = tau; }
+                    sc[kFeasPrev] = feas;
+                    ctrl[kNnot] = nnot; ctrl[kFloor] = floor_hit;
+                    if (bad) ctrl[kSt] |= QPX_ST_NONFINITE;
+                }
             }
-            if (lane == 0) ctrl[0] = stopf;
+            if (lane == 0) ctrl[kStop] = stopf;
         }
         Mat::sync(b);
-        stop = ctrl[0];
+        stop = ctrl[kStop];
         if (stop) break;
         // first pass: z_i = -T^-1 c; iterations: affine scaling direction dz_aff = -T^-1 (c + R z)
+        QPX_PROF(1)
         Mat::solve_neg(b, g, E, rd, m, first ? vC : vRH, vX, vTm, scr);
+        QPX_PROF(6)
         if (first) {
             if (w0) {
                 T x[NS];
@@ -659,17 +693,17 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
                 }
                 mnz = wave_min(b, mnz);
                 mns = wave_min(b, mns);
-                sigz = (mnz < T(0)) ? (T(1) - mnz) : T(0);
-                sigs = (mns < T(0)) ? (T(1) - mns) : T(0);
+                const T sigz = (mnz < T(0)) ? (T(1) - mnz) : T(0);
+                const T sigs = (mns < T(0)) ? (T(1) - mns) : T(0);
+                if (lane == 0) { sc[kSigz] = sigz; sc[kSigs] = sigs; }
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
                     const int i = k * kWave + lane;
                     if (i < m) {
-                        z[k] = x[k] + sigz;
-                        s[k] = -x[k] + sigs;
+                        const T zk = x[k] + sigz, sk = -x[k] + sigs;
+                        vZ[i] = zk; vS[i] = sk;
                         vA[i] = x[k];
-                        vBZ[i] = z[k];
-                        vBS[i] = s[k];
+                        vBZ[i] = zk; vBS[i] = sk;
                     } else if (i < M8) {
                         vA[i] = T(0);
                     }
@@ -679,16 +713,22 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
             QPX_PROF(1)
             continue;
         }
-        T dza[NS], dsa[NS], rs[NS];
         if (w0) {
+            const T mu = sc[kMu], szdot = sc[kSzdot];
+            T z[NS], s[NS], rz[NS], rsv[NS], dd[NS], dza[NS], dsa[NS];
+            ld_slots<NS>(b, z, vZ, m, T(1));
+            ld_slots<NS>(b, s, vS, m, T(1));
+            ld_slots<NS>(b, rz, vRZ, m, T(1));
+            ld_slots<NS>(b, rsv, vRS, m, T(1));
+            ld_slots<NS>(b, dd, vD, m, T(1));
             ld_slots<NS>(b, dza, vX, m, T(0));
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int i = k * kWave + lane;
-                dsa[k] = (i < m) ? (-s[k] - dza[k] * s[k] / z[k]) : T(0);
+                dsa[k] = (i < m) ? (-s[k] - dza[k] * dd[k]) : T(0);
             }
-            T al = step_to_boundary<NS>(b, z, dza, m);
-            const T al2 = step_to_boundary<NS>(b, s, dsa, m);
+            T al = step_to_boundary_rcp<NS>(b, rz, dza, m);
+            const T al2 = step_to_boundary_rcp<NS>(b, rsv, dsa, m);
             al = (al2 < al) ? al2 : al;
             al = (al < T(1)) ? al : T(1);
             T t3 = 0;
@@ -703,52 +743,70 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int i = k * kWave + lane;
-                rs[k] = (i < m) ? ((-mu * sig + dsa[k] * dza[k]) / s[k]) : T(0);
-                if (i < m) vRH[i] = rs[k] * s[k] / z[k];
-            }
-        }
-        Mat::sync(b);
-        Mat::solve_neg(b, g, E, rd, m, vRH, vX, vTm, scr);
-        if (w0) {
-            T dz[NS], ds[NS];
-            ld_slots<NS>(b, dz, vX, m, T(0));
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                const T dsc = (i < m) ? ((-rs[k] - dz[k]) * s[k] / z[k]) : T(0);
-                dz[k] = (i < m) ? (dza[k] + dz[k]) : T(0);
-                ds[k] = dsa[k] + dsc;
-            }
-            T al = step_to_boundary<NS>(b, z, dz, m);
-            const T al3 = step_to_boundary<NS>(b, s, ds, m);
-            al = (al3 < al) ? al3 : al;
-            al = T(0.999) * al;
-            al = (al < T(1)) ? al : T(1);
-            tau = (T(1) - al) * tau;
-            alpha_prev = al;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
                 if (i < m) {
-                    z[k] = fma_(al, dz[k], z[k]);
-                    s[k] = fma_(al, ds[k], s[k]);
-                    vA[i] = z[k] - tau * sigz;
+                    const T rs = (-mu * sig + dsa[k] * dza[k]) * rsv[k];
+                    vRSC[i] = rs;
+                    vRH[i] = rs * dd[k];
+                    vDZA[i] = dza[k];
+                    vDSA[i] = dsa[k];
                 }
             }
         }
         Mat::sync(b);
+        QPX_PROF(1)
+        Mat::solve_neg(b, g, E, rd, m, vRH, vX, vTm, scr);
         QPX_PROF(6)
+        if (w0) {
+            T z[NS], s[NS], rz[NS], rsv[NS], dz[NS], ds[NS];
+            ld_slots<NS>(b, z, vZ, m, T(1));
+            ld_slots<NS>(b, s, vS, m, T(1));
+            ld_slots<NS>(b, rz, vRZ, m, T(1));
+            ld_slots<NS>(b, rsv, vRS, m, T(1));
+            ld_slots<NS>(b, dz, vX, m, T(0));
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                const T dsc = (i < m) ? ((-vRSC[i] - dz[k]) * vD[i]) : T(0);
+                dz[k] = (i < m) ? (vDZA[i] + dz[k]) : T(0);
+                ds[k] = (i < m) ? (vDSA[i] + dsc) : T(0);
+            }
+            T al = step_to_boundary_rcp<NS>(b, rz, dz, m);
+            const T al3 = step_to_boundary_rcp<NS>(b, rsv, ds, m);
+            al = (al3 < al) ? al3 : al;
+            al = T(0.999) * al;
+            al = (al < T(1)) ? al : T(1);
+            const T tau = (T(1) - al) * sc[kTau];
+            const T tsz = tau * sc[kSigz];
+            b.wave_sync();           // every lane has read the old tau
+            if (lane == 0) { sc[kTau] = tau; sc[kAlphaPrev] = al; }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) {
+                    const T zk = fma_(al, dz[k], z[k]);
+                    vZ[i] = zk;
+                    vS[i] = fma_(al, ds[k], s[k]);
+                    vA[i] = zk - tsz;
+                }
+            }
+        }
+        Mat::sync(b);
+        QPX_PROF(1)
     }
 
     // ---- outputs (batch.py:143,207)
     if (w0) {
+        const T bres = sc[kBres];
+        int st = ctrl[kSt];
+        const int iters = ctrl[kIters];
         if (iters >= a.maxIter && !(bres < a.eps)) st |= QPX_ST_MAXITER;
         if (!(bres <= T(1))) st |= QPX_ST_INACCURATE;
+        const T bts = sc[kBtau] * sc[kSigz];
         for (int i = lane; i < m; i += kWave) {
             const T bz = vBZ[i];
             a.lam[(size_t)qp * m + i] = bz;
             a.slack[(size_t)qp * m + i] = vBS[i];
-            vA[i] = bz - btau * sigz;
+            vA[i] = bz - bts;
         }
         if (lane == 0) {
             a.iters[qp] = iters;
@@ -794,11 +852,11 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
 // format-3 blob (see kkt_body for the reference citations):
 //   dz = -T^-1 (M rx + W ry + rs/d - rz),  dx = -K rx - M^T dz - N ry,
 //   dy = S11^-1 ry - N^T rx - W^T dz,      ds = (-rs - dz)/d
-template <class T, int GS, int NBL, bool kBackward>
-QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
+template <class T, class Mat, bool kBackward>
+QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
 {
-    constexpr int M8 = GS * NBL, NT = GS * GS;
-    const GridPos<GS> g(b);
+    constexpr int M8 = Mat::MP, NT = Mat::NT;
+    const typename Mat::Pos g(b);
     const int n = a.n, m = a.m, q = a.q;
     const FacLayout lay = fac_layout(n, m, q);
     T* F = a.fac + (size_t)qp * a.fac_stride;
@@ -815,9 +873,7 @@ QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
     T* vZH = vDY + v;     // zhat (n)   [backward]
     T* vLM = vZH + v;     // lam (m)    [backward]
     T* vNU = vLM + v;     // nu (q)     [backward]
-    T* vec2 = vNU + v;
-    T* dsl = vec2 + 2 * M8;
-    T* red = dsl + 8;
+    T* scr = vNU + v;     // Mat::scratch_elems()
 
     const T* rxg = kBackward ? (a.dl_dz + (size_t)qp * n) : (a.rx ? a.rx + (size_t)qp * n : nullptr);
     const T* rsg = (!kBackward && a.rs) ? a.rs + (size_t)qp * m : nullptr;
@@ -842,34 +898,34 @@ QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
         vD[i] = dinv;
         vRH[i] = rhs;
     }
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     // rhs += M rx + W ry
     block_matTvec<T, 1>(b, vRH, F + lay.MT, vRX, n, m);
     if (q > 0) {
-        GridPos<GS>::sync(b);
+        Mat::sync(b);
         for (int j = b.tid; j < m; j += NT) {
             T acc = vRH[j];
             for (int r = 0; r < q; ++r) acc = fma_(F[lay.W + (size_t)j * q + r], vRY[r], acc);
             vRH[j] = acc;
         }
     }
-    T E[gtri(NBL)];
-    grid_load<T, GS, NBL>(b, E, F + lay.Rg);
-    GridPos<GS>::sync(b);
-    grid_add_diag<T, GS, NBL>(g, E, vD);
-    const bool ok = grid_ldl_inv<T, GS, NBL>(b, g, E, vec2, dsl, rd, m);
+    typename Mat::Regs E;
+    Mat::load(b, g, E, Mat::image(F, lay));
+    Mat::sync(b);
+    Mat::add_diag(g, E, vD);
+    const bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
     if (!ok && b.tid == 0 && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
-    if (ok) grid_solve_neg<T, GS, NBL>(b, g, E, rd, m, vRH, vDZ, vTm, red);
+    if (ok) Mat::solve_neg(b, g, E, rd, m, vRH, vDZ, vTm, scr);
     else {
         for (int i = b.tid; i < M8; i += NT) vDZ[i] = T(0);
-        GridPos<GS>::sync(b);
+        Mat::sync(b);
     }
     // dx = Kneg rx - M^T dz + NTn^T ry     (Kneg = -K, NTn = -N^T)
     block_matTvec<T, 0>(b, vDX, F + lay.Kneg, vRX, n, n);
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     block_matTvec<T, 2>(b, vDX, F + lay.M, vDZ, m, n);
     if (q > 0) {
-        GridPos<GS>::sync(b);
+        Mat::sync(b);
         block_matTvec<T, 1>(b, vDX, F + lay.NTn, vRY, q, n);
         // dy = S11i ry + NTn rx - W^T dz
         for (int r = b.tid; r < q; r += NT) {
@@ -880,7 +936,7 @@ QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
             vDY[r] = acc;
         }
     }
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     if (!kBackward) {
         for (int i = b.tid; i < n; i += NT) a.dx[(size_t)qp * n + i] = vDX[i];
         for (int i = b.tid; i < m; i += NT) {
@@ -903,7 +959,7 @@ QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
         vNU[i] = a.nu[(size_t)qp * q + i];
         a.db[(size_t)qp * q + i] = -vDY[i];
     }
-    GridPos<GS>::sync(b);
+    Mat::sync(b);
     T* dQ = a.dQ + (size_t)qp * n * n;
     for (int idx = b.tid; idx < n * n; idx += NT) {
         const int r = idx / n, c = idx - r * n;
@@ -923,11 +979,22 @@ QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
     }
 }
 
+template <class T, int GS, int NBL, bool kBackward>
+QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
+{
+    kkt_mat_body<T, GridMat<T, GS, NBL>, kBackward>(b, a, qp, lds);
+}
+
+// LDS elements of the KKT-solve / backward kernel: 12 vectors + the matrix operations' scratch
+QPX_LAYOUT_HD size_t lds_elems_kkt_mat(size_t mp, size_t scratch, int n, int q)
+{
+    const size_t v = align4(max2(max2((size_t)n, mp), (size_t)q));
+    return 12 * v + scratch;
+}
 QPX_LAYOUT_HD size_t lds_elems_kkt_grid(int gs, int nbl, int n, int q)
 {
     const size_t mg = (size_t)gs * nbl;
-    const size_t v = align4(max2(max2((size_t)n, mg), (size_t)q));
-    return 12 * v + 2 * mg + 8 + (size_t)nbl * gs * gs;
+    return lds_elems_kkt_mat(mg, 2 * mg + 4 + (size_t)nbl * gs * gs, n, q);
 }
 
 }  // namespace qpx

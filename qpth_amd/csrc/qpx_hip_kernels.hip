@@ -208,6 +208,27 @@ extern "C" int qpx_panel_prof_read(unsigned long long* out)
     return 0;
 }
 #endif
+template <int NBL, int NW, bool kBw>
+__global__ __launch_bounds__(64 * NW, (NW <= 2 && NBL > 4) ? 1 : 2) void k_kkt_tile(KktArgs<double> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    kkt_tile_body<NBL, NW, kBw>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+}
+template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_kkt_tile<NBL, NW, kBw>;
+    static bool big_lds_enabled = false;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NW), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTK(NBL, NW)                                                                     \
+    template int launch_kkt_tile<NBL, NW, false>(const KktArgs<double>&, size_t, void*);       \
+    template int launch_kkt_tile<NBL, NW, true>(const KktArgs<double>&, size_t, void*);
+#ifndef QPX_TILE_ONLY
+QPX_INSTK(1, 1) QPX_INSTK(2, 1) QPX_INSTK(4, 1) QPX_INSTK(4, 2) QPX_INSTK(7, 1) QPX_INSTK(7, 2) QPX_INSTK(7, 4)
+#endif
 #define QPX_INSTT(NBL, NW, NS) template int launch_ipm_tile<NBL, NW, NS>(const IpmArgs<double>&, size_t, void*);
 #ifdef QPX_TILE_ONLY
 QPX_INSTT(7, QPX_TILE_ONLY, 2)

@@ -57,6 +57,7 @@ template <class T> QPX_DEV T wave_sum(const Block& b, T v)
     return (b.bcast(v, 0) + b.bcast(v, 16)) + (b.bcast(v, 32) + b.bcast(v, 48));
 }
 template <class T> QPX_DEV T min2_(T a, T c) { return (c < a) ? c : a; }
+template <class T> QPX_DEV T max2_(T a, T c) { return (c > a) ? c : a; }
 template <class T> QPX_DEV T wave_min(const Block& b, T v)
 {
     v = min2_(v, b.template xor16<1>(v));
@@ -64,6 +65,14 @@ template <class T> QPX_DEV T wave_min(const Block& b, T v)
     v = min2_(v, b.template xor16<7>(v));
     v = min2_(v, b.template xor16<15>(v));
     return min2_(min2_(b.bcast(v, 0), b.bcast(v, 16)), min2_(b.bcast(v, 32), b.bcast(v, 48)));
+}
+template <class T> QPX_DEV T wave_max(const Block& b, T v)
+{
+    v = max2_(v, b.template xor16<1>(v));
+    v = max2_(v, b.template xor16<2>(v));
+    v = max2_(v, b.template xor16<7>(v));
+    v = max2_(v, b.template xor16<15>(v));
+    return max2_(max2_(b.bcast(v, 0), b.bcast(v, 16)), max2_(b.bcast(v, 32), b.bcast(v, 48)));
 }
 
 // A vector of length n is held by ONE wave as NS registers per lane: element i lives in
@@ -278,6 +287,7 @@ template <class T> struct PrefactorArgs {
     T* fac;
     size_t fac_stride;
     int* status;
+    int images;                           // sweep path: which register images of R to write (1 Rg, 2 Rw, 4 Rm)
 };
 
 template <class T> struct IpmArgs {
@@ -552,6 +562,22 @@ QPX_DEV T step_to_boundary(const Block& b, const T (&v)[NS], const T (&dv)[NS], 
     }
     r = wave_min(b, r);
     return (r == Lim<T>::inf()) ? T(1) : r;
+}
+
+// The same step length from the reciprocals rv = 1/v the caller already holds: the minimum of -v/dv
+// is the reciprocal of the maximum of -dv/v, so the per-entry divisions become multiplications and
+// one division remains (f64 division is a ~15-instruction sequence on gfx950).
+template <int NS, class T>
+QPX_DEV T step_to_boundary_rcp(const Block& b, const T (&rv)[NS], const T (&dv)[NS], int m)
+{
+    T t = T(0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = s * kWave + b.lane();
+        if (i < m && dv[s] < T(0)) t = max2_(t, -dv[s] * rv[s]);
+    }
+    t = wave_max(b, t);
+    return (t > T(0)) ? T(1) / t : T(1);
 }
 
 // Solve T dz = -rhs with the factored T = L_T L_T^T (wave 0).

@@ -381,7 +381,7 @@ template <int NBL, int NW> struct TileMat {
             }
         }
         row_reduce(blk, p, acc, scr, [&](int i, T s) { tmp[i] = (i < m) ? (s + vin[i]) * rd[i] : T(0); });
-        sync(blk);
+        blk.wave_sync();      // a wave owns whole tile rows: the u it reads next are the ones it just wrote
         // x = W~^T u: sums down columns, partial per wave, gathered in a fixed order
         T u[NPOS][4];
 #pragma unroll
@@ -416,6 +416,18 @@ QPX_LAYOUT_HD size_t lds_elems_ipm_tile(int nbl, int nw, int n, int q)
 {
     const size_t mp = 16 * (size_t)nbl, npos = (size_t)(nbl + nw - 1) / nw;
     return lds_elems_ipm_loop(mp, 8 * mp + 32 + (size_t)nw * nbl * 64 + (size_t)nw * 16 * npos * 17 + mp, n, q);
+}
+
+QPX_LAYOUT_HD size_t lds_elems_kkt_tile(int nbl, int nw, int n, int q)
+{
+    const size_t mp = 16 * (size_t)nbl, npos = (size_t)(nbl + nw - 1) / nw;
+    return lds_elems_kkt_mat(mp, 8 * mp + 32 + (size_t)nw * nbl * 64 + (size_t)nw * 16 * npos * 17 + mp, n, q);
+}
+
+template <int NBL, int NW, bool kBackward>
+QPX_DEV void kkt_tile_body(const Block& b, const KktArgs<double>& a, int qp, double* lds)
+{
+    kkt_mat_body<double, TileMat<NBL, NW>, kBackward>(b, a, qp, lds);
 }
 
 template <int NBL, int NW, int NS>

@@ -13,7 +13,7 @@ import problems  # noqa: E402
 from qpth_amd import _lib  # noqa: E402
 from qpth_amd.kkt import KKTFactors  # noqa: E402
 
-NAMES = ["consts(p,h,b)", "start point", "copy R->T", "symv R z'", "residuals(w0)", "cholesky", "newton(w0)", "epilogue"]
+NAMES = ["consts(p,h,b)", "vector work (w0)", "copy R->T", "symv R z'", "residuals(w0)", "factorisation", "solves", "epilogue"]
 
 
 def main():
@@ -44,7 +44,7 @@ def main():
     print("B=%d n=%d m=%d q=%d %s  iterations mean %.2f  total cycles/QP mean %.0f max %.0f" % (
         B, n, m, q, dt.__name__, iters.mean(), tot.mean(), tot.max()))
     for i, nm in enumerate(NAMES):
-        per_it = cyc[:, i].mean() / iters.mean() if 2 <= i <= 6 else float("nan")
+        per_it = cyc[:, i].mean() / (iters.mean() + 1) if 1 <= i <= 6 else float("nan")
         print("  %-16s %12.0f cycles (%5.1f%%)   per iteration %10.0f" % (nm, cyc[:, i].mean(), 100 * cyc[:, i].sum() / tot.sum(), per_it))
 
 
