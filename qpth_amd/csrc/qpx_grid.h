@@ -258,7 +258,8 @@ template <class T, int GS, int NBL> struct GridMat {
 // words, scratch
 QPX_LAYOUT_HD size_t lds_elems_ipm_loop(size_t mp, size_t scratch, int n, int q)
 {
-    const size_t v = align4(max2(max2((size_t)n, mp), (size_t)q));
+    const size_t d = max2(max2((size_t)n, mp), (size_t)q);
+    const size_t v = d <= 64 ? 64 : (d <= 128 ? 128 : (d <= 256 ? 256 : 512));    // 64 NS, see ipm_loop_body
     return 19 * v + 24 + scratch;
 }
 QPX_LAYOUT_HD size_t lds_elems_ipm_grid(int gs, int nbl, int n, int q)
@@ -497,7 +498,10 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     const FacLayout lay = fac_layout(n, m, q);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const T* Rg = Mat::image(F, lay);
-    const size_t v = align4(max2(max2((size_t)n, (size_t)M8), (size_t)q));
+    // compile-time vector stride (64 NS >= max(n, MP, q)): every LDS vector is then a constant offset
+    // from one base and the compiler addresses them all with one lane register + immediates (with a
+    // run-time stride it hoisted ~40 per-vector address registers out of the loop and spilled them)
+    constexpr size_t v = 64 * (size_t)NS;
     T* rd = lds;          // 1/d_k (M8)
     T* vA = rd + v;       // z' (M8)
     T* vB = vA + v;       // R z' (M8)

@@ -30,7 +30,7 @@
 //
 // NW waves share a QP (NW = 1, 2 or 4).  Tile rows are dealt round-robin from the bottom: wave w
 // owns rows I_p = NBL-1 - p NW - (w or NW-1-w, alternating), p = 0 .. NPOS-1 ("positions"), and keeps tile (I_p, J) in
-// register slot pbase(p) + J -- a static index for static (p, J); which row a position is, is a
+// register slot slot(p, J) -- a static index for static (p, J); which row a position is, is a
 // wave-uniform scalar (a compile-time constant when NW = 1).  The tile row Ip of the current
 // panel is a run-time value (the panel code exists 4 times -- once per register index SP --
 // not 4 NBL times), tests against it are scalar branches.
@@ -61,14 +61,32 @@ namespace qpx {
 template <int NBL, int NW> struct TileMat {
     using T = double;
     static constexpr int NPOS = (NBL + NW - 1) / NW, NT = 64 * NW, MP = 16 * NBL;
-    static constexpr int psize(int p) { return NBL - p * NW; }            // tiles of position p (wave 0: the longest)
-    static constexpr int pbase(int p)
+    static constexpr int psize(int p) { return NBL - p * NW; }            // tiles of position p at most (over the waves)
+    static constexpr int rowof(int p, int w) { return NBL - 1 - p * NW - ((p & 1) ? NW - 1 - w : w); }
+    // Positions 2k and 2k+1 share one run of slots: 2k fills it from the bottom (slot = base + J), 2k+1
+    // from the top (base + size - 1 - J).  In snake order their tile counts add up to the same number
+    // for every wave, so nothing is wasted (NBL = 7, NW = 4: 7 slots per wave instead of 7 + 3).
+    static constexpr int pairsize(int k)
+    {
+        int best = 0;
+        for (int w = 0; w < NW; ++w) {
+            const int a = rowof(2 * k, w) + 1 > 0 ? rowof(2 * k, w) + 1 : 0;
+            const int c = (2 * k + 1 < NPOS && rowof(2 * k + 1, w) + 1 > 0) ? rowof(2 * k + 1, w) + 1 : 0;
+            best = a + c > best ? a + c : best;
+        }
+        return best;
+    }
+    static constexpr int pairbase(int k)
     {
         int b = 0;
-        for (int k = 0; k < p; ++k) b += psize(k);
+        for (int i = 0; i < k; ++i) b += pairsize(i);
         return b;
     }
-    static constexpr int NSLOT = pbase(NPOS);
+    static constexpr int slot(int p, int J)
+    {
+        return (p & 1) ? pairbase(p / 2) + pairsize(p / 2) - 1 - J : pairbase(p / 2) + J;
+    }
+    static constexpr int NSLOT = pairbase((NPOS + 1) / 2);
     static constexpr int minrow(int p) { return NBL - 1 - p * NW - (NW - 1); }   // smallest row any wave has at position p
     static constexpr int NROW = 16 * NPOS;                                 // matrix rows a wave owns (at most)
     struct Pos {
@@ -80,7 +98,7 @@ template <int NBL, int NW> struct TileMat {
         }
         // tile row of position p (< 0: none).  Rows are dealt from the bottom in snake order (w, then
         // NW-1-w, ...) so that the tile counts of the waves stay close as the factorisation retires rows
-        QPX_DEV int row(int p) const { return NBL - 1 - p * NW - ((p & 1) ? NW - 1 - w : w); }
+        QPX_DEV int row(int p) const { return NBL - 1 - p * NW - ((p & 1) ? NW - 1 - w : w); }   // = rowof(p, w)
     };
     struct Regs { T e[NSLOT][4]; };
     // scratch: X (2 x 4 x MP) | S (2 x 16) | part (NW x NBL x 64) | red (NW x NROW x 17) | yrow (MP)
@@ -104,10 +122,7 @@ template <int NBL, int NW> struct TileMat {
             for (int J = 0; J < psize(pp); ++J) {
                 if (J <= I) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) E.e[pbase(pp) + J][r] = rows.row((I * (I + 1) / 2 + J) * 4 + r);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) E.e[pbase(pp) + J][r] = T(0);
+                    for (int r = 0; r < 4; ++r) E.e[slot(pp, J)][r] = rows.row((I * (I + 1) / 2 + J) * 4 + r);
                 }
             }
         }
@@ -123,7 +138,7 @@ template <int NBL, int NW> struct TileMat {
                 if (J != I) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (p.c == p.g + 4 * r) E.e[pbase(pp) + J][r] += vd[16 * J + p.c];
+                    if (p.c == p.g + 4 * r) E.e[slot(pp, J)][r] += vd[16 * J + p.c];
             }
         }
     }
@@ -193,10 +208,10 @@ template <int NBL, int NW> struct TileMat {
                 const int I = p.row(pp);
                 if (J > I) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[pp][r] = fma_(E.e[pbase(pp) + J][r], xj, acc[pp][r]);
+                for (int r = 0; r < 4; ++r) acc[pp][r] = fma_(E.e[slot(pp, J)][r], xj, acc[pp][r]);
                 if (J < I) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) col = fma_(E.e[pbase(pp) + J][r], u[pp][r], col);
+                    for (int r = 0; r < 4; ++r) col = fma_(E.e[slot(pp, J)][r], u[pp][r], col);
                 }
             }
             part[(size_t)(p.w * NBL + J) * 64 + p.lane] = col;
@@ -224,7 +239,7 @@ template <int NBL, int NW> struct TileMat {
             if (p.row(pp) != Ip) continue;
 #pragma unroll
             for (int J = 0; J < psize(pp); ++J)
-                if (J <= Ip) X[p.g * MP + 16 * J + p.c] = E.e[pbase(pp) + J][SP];
+                if (J <= Ip) X[p.g * MP + 16 * J + p.c] = E.e[slot(pp, J)][SP];
         }
         // ... the pivot block (identity in X, the block itself in S) and the four columns below it.
         // Row g + 4 r of tile row I lies below the panel iff I > Ip or r > SP.  The panel's own columns
@@ -239,13 +254,13 @@ template <int NBL, int NW> struct TileMat {
                     const int I = p.row(pp);
                     if (I < Ip) continue;
                     if (I == Ip) {
-                        S[p.g * 4 + kc] = E.e[pbase(pp) + J][SP];
+                        S[p.g * 4 + kc] = E.e[slot(pp, J)][SP];
                         X[p.g * MP + 16 * J + p.c] = (kc == p.g) ? T(1) : T(0);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (I > Ip || r > SP) X[kc * MP + 16 * I + p.g + 4 * r] = E.e[pbase(pp) + J][r];
-                        E.e[pbase(pp) + J][r] = T(0);
+                        if (I > Ip || r > SP) X[kc * MP + 16 * I + p.g + 4 * r] = E.e[slot(pp, J)][r];
+                        E.e[slot(pp, J)][r] = T(0);
                     }
                 }
             }
@@ -305,12 +320,13 @@ template <int NBL, int NW> struct TileMat {
         QPX_PP(3)
         // -- the panel's own rows are final: W~ rows left of the panel, L~_pp^-1 inside it.  (The diagonal
         // entries get the 1 of the unit factor; the d_k live in rd[] as reciprocals, E's diagonal is never
-        // read after the factorisation.  Slots right of the diagonal tile are unused, writing them is free.)
+        // read after the factorisation.)
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
             if (p.row(pp) != Ip) continue;
 #pragma unroll
-            for (int J = 0; J < psize(pp); ++J) E.e[pbase(pp) + J][SP] = bop[J];
+            for (int J = 0; J < psize(pp); ++J)
+                if (J <= Ip) E.e[slot(pp, J)][SP] = bop[J];
         }
         // -- rank-4 update of every owned tile at or below the panel's tile row
 #pragma unroll
@@ -319,7 +335,7 @@ template <int NBL, int NW> struct TileMat {
             if (I < Ip) continue;
 #pragma unroll
             for (int J = 0; J < psize(pp); ++J)
-                if (J <= minrow(pp) || J <= I) blk.mfma16x16x4(aop[pp], bop[J], E.e[pbase(pp) + J]);
+                if (J <= minrow(pp) || J <= I) blk.mfma16x16x4(aop[pp], bop[J], E.e[slot(pp, J)]);
         }
         QPX_PP(4)
         return true;
@@ -375,7 +391,7 @@ template <int NBL, int NW> struct TileMat {
                 if (J > I) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const T e = (J < I || p.c < p.g + 4 * r) ? E.e[pbase(pp) + J][r] : T(0);
+                    const T e = (J < I || p.c < p.g + 4 * r) ? E.e[slot(pp, J)][r] : T(0);
                     acc[pp][r] = fma_(e, xj, acc[pp][r]);
                 }
             }
@@ -400,7 +416,7 @@ template <int NBL, int NW> struct TileMat {
                 if (J > I) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const T e = (J < I || p.c < p.g + 4 * r) ? E.e[pbase(pp) + J][r] : T(0);
+                    const T e = (J < I || p.c < p.g + 4 * r) ? E.e[slot(pp, J)][r] : T(0);
                     col = fma_(e, u[pp][r], col);
                 }
             }
