@@ -43,6 +43,21 @@ def _is_shared(X, B):
     return X.dim() == 2 or X.stride(0) == 0 or (B > 1 and X.size(0) == 1)
 
 
+_PINNED = {}
+
+
+def _pinned_slot(device, nslots=256):
+    """One int32 of pinned host memory from a small per-device ring (allocating pinned memory per call
+    would cost more than the kernels it lets us overlap)."""
+    key = (device.type, device.index)
+    ring = _PINNED.get(key)
+    if ring is None:
+        ring = _PINNED[key] = [torch.zeros(nslots, dtype=torch.int32).pin_memory(), 0]
+    i = ring[1]
+    ring[1] = (i + 1) % nslots
+    return ring[0][i]
+
+
 class KKTFactors:
     def __init__(self):
         self.d = None
@@ -72,11 +87,26 @@ class KKTFactors:
         self.lib.pre_factor(nblob, self.n, self.m, self.q, Q, G, A if self.q else None, self.blob, self.status)
         if self.shared:
             self.status[1:] = self.status[0]
+        # The reference raises on a bad Q / A from inside forward (qp.py:81-85, batch.py:379-386).  The two
+        # status bits that matter are final once the pre-factorisation kernel has run, so their maximum is
+        # copied to pinned host memory right behind it and read (raise_on_failure) after the loop kernel
+        # has been enqueued: the host waits for the pre-factorisation only, never for the IPM loop.
+        self._pre_flag = torch.max(self.status & (_lib.ST_Q_NOT_SPD | _lib.ST_A_RANK))
+        self._pre_host = self._pre_event = None
+        if self._pre_flag.is_cuda:
+            self._pre_host = _pinned_slot(self.device)
+            self._pre_host.copy_(self._pre_flag, non_blocking=True)
+            self._pre_event = torch.cuda.Event()
+            self._pre_event.record(torch.cuda.current_stream(self.device))
         return self
 
     # -- error surface of pre_factor_kkt / QPFunction (qp.py:81-85, batch.py:379-386) ------
     def raise_on_failure(self, check_Q_spd=False):
-        st = int(torch.max(self.status & (_lib.ST_Q_NOT_SPD | _lib.ST_A_RANK)).item())
+        if self._pre_event is not None:
+            self._pre_event.synchronize()
+            st = int(self._pre_host)
+        else:
+            st = int(self._pre_flag.item())
         if st & _lib.ST_Q_NOT_SPD:
             if check_Q_spd:
                 raise RuntimeError('Q is not SPD.')
