@@ -88,7 +88,8 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * pre-factorisation/backward + the one-wave-per-QP loop (nineq <= 104, nz <= 128).
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
- * at 1 / 2 / 4; by default the library picks by dtype, size and batch.
+ * at 1 / 2 / 4, adding 16384 selects the (slower, experimental) tile pre-factorisation instead of the
+ * thread-grid sweep; by default the library picks by dtype, size and batch.
  * The knob must not change between qpx_pre_factor and the calls that consume its factors.
  * Returns the previous value. */
 int qpx_set_ipm_variant(int variant);
