@@ -37,7 +37,7 @@
  *                 2 "round-off floor" rule (the default of the HIP path for B > 1): in exact
  *                   arithmetic the feasibility residual obeys feas_{k+1} = (1-alpha_k) feas_k;
  *                   once the measured one exceeds twice that prediction it is round-off, and
- *                   the QP stops as soon as nineq*mu < 1e-4 * feas.  The not-improved counter
+ *                   the QP stops as soon as nineq*mu < 1e-2 * feas.  The not-improved counter
  *                   only counts while nineq*mu < feas.
  *
  * The source is compiled twice (REAL=double / REAL=float); symbols carry SUFFIX.
@@ -518,7 +518,7 @@ int FN(qpo_forward)(int B, int n, int m, int q, const real *Q, const real *p, co
                 feas_prev[i] = feas;
                 if ((stall_policy != 0 && nnot[i] >= notImprovedLim) || best_resid[i] < (real)eps ||
                     mu[i] > (real)1e32 || !isfinite((double)resid[i]) ||
-                    (stall_policy == 2 && floor_hit[i] && m * mu[i] < (real)1e-4 * feas))
+                    (stall_policy == 2 && floor_hit[i] && m * mu[i] < (real)1e-2 * feas))
                     active[i] = 0;
             }
         }

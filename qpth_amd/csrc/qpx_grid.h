@@ -661,7 +661,7 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
                 }
                 if (a.stall_policy == 2 && it >= 1 && feas > T(2) * (T(1) - sc[kAlphaPrev]) * sc[kFeasPrev]) floor_hit = 1;
                 if ((a.stall_policy != 0 && nnot >= a.notImprovedLim) || bres < a.eps || mu > T(1e32)) stopf = 1;
-                if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-4) * feas) stopf = 1;
+                if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-2) * feas) stopf = 1;
                 const bool bad = !finite_(resid);
                 if (bad) stopf = 1;
                 b.wave_sync();       // every lane has read the scalars lane 0 is about to replace

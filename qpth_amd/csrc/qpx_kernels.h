@@ -813,7 +813,7 @@ QPX_DEV void ipm_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
                 feas_prev = feas;
                 if ((a.stall_policy != 0 && nnot >= a.notImprovedLim) || bres < a.eps || mu > T(1e32))
                     stopf = 1;                                       // batch.py:140
-                if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-4) * feas) stopf = 1;
+                if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-2) * feas) stopf = 1;
                 if (!finite_(resid)) { stopf = 1; st |= QPX_ST_NONFINITE; }
             }
             if (!stopf) {
