@@ -181,10 +181,13 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
 #define QPX_INSTG(NBL, NS) template int launch_ipm_grid8<QPX_TU_REAL, NBL, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) QPX_INSTG(8, 2) QPX_INSTG(13, 2)
 #elif QPX_TU_KERNEL == 9
-// NW waves per QP.  Two waves per SIMD (<= 256 registers per lane) except for the one-wave form at
-// the largest size, whose 28 tiles alone are 224 registers.
+// NW waves per QP, always at least two waves per SIMD (<= 256 registers per lane): at that occupancy the
+// compiler keeps MFMA accumulators in VGPRs.  (At one wave per SIMD it moves every tile through AGPRs --
+// 16 copies and a full-latency stall per MFMA -- and the flag that forbids it, -amdgpu-mfma-vgpr-form,
+// crashes clang 22 on some instantiations; so the one-wave form is not built for NBL = 7, whose 28
+// tiles alone are 224 registers.)
 template <int NBL, int NW, int NS>
-__global__ __launch_bounds__(64 * NW, (NW <= 2 && NBL > 4) ? 1 : 2) void k_ipm_tile(IpmArgs<double> a)
+__global__ __launch_bounds__(64 * NW, 2) void k_ipm_tile(IpmArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
@@ -209,7 +212,7 @@ extern "C" int qpx_panel_prof_read(unsigned long long* out)
 }
 #endif
 template <int NBL, int NW, bool kBw>
-__global__ __launch_bounds__(64 * NW, (NW <= 2 && NBL > 4) ? 1 : 2) void k_kkt_tile(KktArgs<double> a)
+__global__ __launch_bounds__(64 * NW, 2) void k_kkt_tile(KktArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
@@ -227,11 +230,11 @@ template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& 
     template int launch_kkt_tile<NBL, NW, false>(const KktArgs<double>&, size_t, void*);       \
     template int launch_kkt_tile<NBL, NW, true>(const KktArgs<double>&, size_t, void*);
 #if !defined(QPX_TILE_ONLY) && !defined(QPX_TILE_PRE_ONLY)
-QPX_INSTK(1, 1) QPX_INSTK(2, 1) QPX_INSTK(4, 1) QPX_INSTK(4, 2) QPX_INSTK(7, 1) QPX_INSTK(7, 2) QPX_INSTK(7, 4)
+QPX_INSTK(1, 1) QPX_INSTK(2, 1) QPX_INSTK(4, 1) QPX_INSTK(4, 2) QPX_INSTK(7, 2) QPX_INSTK(7, 4)
 #endif
 // pre-factorisation on tiles: the augmented matrix (order <= 208) needs up to 91 tiles = 13 per wave at 8 waves
 template <int NBL, int NW>
-__global__ __launch_bounds__(64 * NW, (NW >= 8 || (NW <= 2 && NBL > 4)) ? 1 : 2) void k_prefactor_tile(PrefactorArgs<double> a)
+__global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void k_prefactor_tile(PrefactorArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
@@ -258,7 +261,7 @@ QPX_INSTT(7, QPX_TILE_ONLY, 2)
 #else
 QPX_INSTT(1, 1, 1) QPX_INSTT(1, 1, 2) QPX_INSTT(1, 1, 4) QPX_INSTT(2, 1, 1) QPX_INSTT(2, 1, 2) QPX_INSTT(2, 1, 4)
 QPX_INSTT(4, 1, 1) QPX_INSTT(4, 1, 2) QPX_INSTT(4, 1, 4) QPX_INSTT(4, 2, 1) QPX_INSTT(4, 2, 2) QPX_INSTT(4, 2, 4)
-QPX_INSTT(7, 1, 2) QPX_INSTT(7, 1, 4) QPX_INSTT(7, 2, 2) QPX_INSTT(7, 2, 4) QPX_INSTT(7, 4, 2) QPX_INSTT(7, 4, 4)
+QPX_INSTT(7, 2, 2) QPX_INSTT(7, 2, 4) QPX_INSTT(7, 4, 2) QPX_INSTT(7, 4, 4)
 #endif
 #endif
 

@@ -145,7 +145,9 @@ QPX_DEV double rcp_(double x)
 #endif
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+#ifndef QPX_RCP_ONE_NEWTON
     r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+#endif
     return r;
 }
 QPX_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of two builds of the library ON THE SAME BOX (boxes of the pool differ by ~6 % in clocks):
-ab_bench.py <libA.so> <libB.so> [B n m q]  -- fwd+bwd ms per step and the loop kernel's ms, alternating."""
+ab_bench.py <libA.so> <libB.so> ... [B n m q]  -- fwd+bwd ms per step and the loop kernel's ms, alternating."""
 import os
 import sys
 import time
@@ -15,8 +15,9 @@ from qpth_amd import _lib  # noqa: E402
 from qpth_amd.kkt import KKTFactors  # noqa: E402
 from qpth_amd.qp import QPFunction  # noqa: E402
 
-libs = sys.argv[1:3]
-B, n, m, q = [int(x) for x in (sys.argv[3:7] if len(sys.argv) > 6 else (512, 100, 100, 0))]
+libs = [x for x in sys.argv[1:] if x.endswith('.so')]
+dims = [x for x in sys.argv[1:] if not x.endswith('.so')]
+B, n, m, q = [int(x) for x in (dims if len(dims) == 4 else (512, 100, 100, 0))]
 dev = torch.device("cuda:0")
 Q, p, G, h, A, b = [torch.tensor(x, device=dev) for x in problems.prof_qp(B, n, m, q, 0)]
 p.requires_grad_(True)
