@@ -123,7 +123,7 @@ template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t l
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
 #define QPX_INSTG(NBL) template int launch_sweep<QPX_TU_REAL, NBL>(const PrefactorArgs<QPX_TU_REAL>&, size_t, void*);
-QPX_INSTG(1) QPX_INSTG(2) QPX_INSTG(4) QPX_INSTG(7) QPX_INSTG(10) QPX_INSTG(13)
+QPX_INSTG(1) QPX_INSTG(2) QPX_INSTG(4) QPX_INSTG(7) QPX_INSTG(8) QPX_INSTG(10) QPX_INSTG(13)
 #elif QPX_TU_KERNEL == 6
 // two workgroups per CU (2 waves per SIMD) for the common sizes: the two QPs hide each other's
 // barrier / LDS latencies

@@ -81,6 +81,15 @@ QPX_LAYOUT_HD size_t tile_image_index(int i, int j)   // i >= j, or both in the 
     return ((size_t)(I * (I + 1) / 2 + J) * 4 + (ri >> 2)) * 64 + (size_t)((ri & 3) * 16 + c);
 }
 
+// Blocks of 16 the sweep pre-factorisation is instantiated with for the augmented order n+q+m: the
+// grid_nb list plus 8 (C5: 64 + 64 = 128 is exactly 8 blocks; rounding it up to 10 would sweep 55 blocks
+// per thread instead of 36).
+QPX_LAYOUT_HD int sweep_nb(int ord)
+{
+    const int need = (ord + 15) / 16;
+    return need == 8 ? 8 : grid_nb(ord);
+}
+
 struct FacLayout {
     size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, Rw;
     // "format 3" (grid kernels: sweep pre-factorisation, no triangular factors), present when
