@@ -384,6 +384,7 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
     T* vout = dsl + 8;             // MA
     T* red = vout + MA;            // NBL*256
 
+    QPX_PROF_INIT
     T E[gtri(NBL)];
     // ---- load the lower triangle of S (diagonal blocks in full)
 #pragma unroll
@@ -394,12 +395,13 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
             if (j > i) { const int t = i; i = j; j = t; }       // upper part of a diagonal block: mirror
             T val = T(0);
             if (i < na && j < n) {
-                if (i < n) val = T(0.5) * (Qg[(size_t)i * n + j] + Qg[(size_t)j * n + i]);
+                if (i < n) val = Qg[(size_t)j * n + i];      // Q by its upper triangle: the coalesced read (lanes run over i)
                 else if (i < nq) val = Ag[(size_t)(i - n) * n + j];
                 else val = Gg[(size_t)(i - nq) * n + j];
             }
             E[gidx(li, lj)] = val;
         }
+    QPX_PROF(0)
     // ---- || G^T 1 ||  (column sums of the G block, before it is swept)
     {
         T part[NBL];
@@ -420,6 +422,7 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
             if (blk.lane() == 0) F[lay.scal] = sqrt_(acc);
         }
     }
+    QPX_PROF(1)
     // ---- sweep pivots 0 .. n+q-1 (static block index via template recursion, see SweepBlocks)
     const int fail = SweepBlocks<T, NBL, 0>::run(blk, g, E, vec2, dsl, n, nq);
     GridPos<GS>::sync(blk);
@@ -428,6 +431,7 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
         if (blk.tid == 0) a.status[qp] = fail;
         return;
     }
+    QPX_PROF(2)
     // ---- scatter the blocks of the swept matrix to the blob
     const bool wRg = (a.images & 1) != 0, wRw = (a.images & 2) != 0 && lay.nbw > 0, wRm = (a.images & 4) != 0 && lay.nbt > 0;
     if (wRg)
@@ -481,6 +485,11 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
                 }
             }
         }
+    QPX_PROF(3)
+    {
+        const Block& b = blk;
+        QPX_PROF_DUMP(F + lay.T, T)
+    }
     if (blk.tid == 0) a.status[qp] = 0;
 }
 

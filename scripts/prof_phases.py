@@ -34,10 +34,15 @@ def main():
     pn = ["load Q + chol(Q)", "load G^T, |G^T 1|", "TRSM Z=L^-1 G^T", "equality block", "SYRK R=Z^T Z", "r1 + spill to blob", "-", "-"]
     if lib.dll.qpx_set_ipm_variant(int(os.environ.get("QPX_VARIANT", "0"))) is None:
         pass
-    if int(os.environ.get("QPX_VARIANT", "0")) != 0:
+    if int(os.environ.get("QPX_VARIANT", "0")) in (1, 2):
         print("k_prefactor: total cycles/QP mean %.0f" % pre.sum(1).mean())
         for i in range(6):
             print("  %-20s %12.0f cycles (%5.1f%%)" % (pn[i], pre[:, i].mean(), 100 * pre[:, i].sum() / pre.sum()))
+    else:
+        sn = ["load Q, G, A", "|| G^T 1 ||", "sweep n+q pivots", "scatter to the blob"]
+        print("k_sweep: total cycles/QP mean %.0f" % pre[:, :4].sum(1).mean())
+        for i in range(4):
+            print("  %-20s %12.0f cycles (%5.1f%%)" % (sn[i], pre[:, i].mean(), 100 * pre[:, i].sum() / pre[:, :4].sum()))
     cyc = res.trace.reshape(-1)[:B * 8].reshape(B, 8).double().cpu().numpy()
     iters = res.iters.cpu().numpy()
     tot = cyc.sum(1)
