@@ -6,6 +6,7 @@ backward (qpth/qp.py:93,150-155): here one HBM blob per QP written by qpx_pre_fa
 are all shared by the batch (un-batched parameters, qpth/util.py:44-50) the blob is built
 once and every workgroup reads the same copy.
 """
+import numpy as np
 import torch
 
 from . import _lib
@@ -46,15 +47,15 @@ def _is_shared(X, B):
 _PINNED = {}
 
 
-def _pinned_slot(device, nslots=256):
-    """One int32 of pinned host memory from a small per-device ring (allocating pinned memory per call
-    would cost more than the kernels it lets us overlap)."""
-    key = (device.type, device.index)
+def _pinned_ints(device, count, nring=16):
+    """`count` int32 of pinned host memory from a small ring per (device, count): allocating pinned
+    memory per call would cost more than the kernels it lets us overlap."""
+    key = (device.type, device.index, int(count))
     ring = _PINNED.get(key)
     if ring is None:
-        ring = _PINNED[key] = [torch.zeros(nslots, dtype=torch.int32).pin_memory(), 0]
+        ring = _PINNED[key] = [[torch.zeros(count, dtype=torch.int32).pin_memory() for _ in range(nring)], 0]
     i = ring[1]
-    ring[1] = (i + 1) % nslots
+    ring[1] = (i + 1) % nring
     return ring[0][i]
 
 
@@ -88,25 +89,26 @@ class KKTFactors:
         if self.shared:
             self.status[1:] = self.status[0]
         # The reference raises on a bad Q / A from inside forward (qp.py:81-85, batch.py:379-386).  The two
-        # status bits that matter are final once the pre-factorisation kernel has run, so their maximum is
+        # status bits that matter are final once the pre-factorisation kernel has run, so the status words are
         # copied to pinned host memory right behind it and read (raise_on_failure) after the loop kernel
         # has been enqueued: the host waits for the pre-factorisation only, never for the IPM loop.
-        self._pre_flag = torch.max(self.status & (_lib.ST_Q_NOT_SPD | _lib.ST_A_RANK))
         self._pre_host = self._pre_event = None
-        if self._pre_flag.is_cuda:
-            self._pre_host = _pinned_slot(self.device)
-            self._pre_host.copy_(self._pre_flag, non_blocking=True)
+        if self.status.is_cuda:
+            # one DMA of the per-QP status words, no reduction kernels in the stream
+            self._pre_host = _pinned_ints(self.device, nblob)
+            self._pre_host.copy_(self.status[:nblob], non_blocking=True)
             self._pre_event = torch.cuda.Event()
             self._pre_event.record(torch.cuda.current_stream(self.device))
         return self
 
     # -- error surface of pre_factor_kkt / QPFunction (qp.py:81-85, batch.py:379-386) ------
     def raise_on_failure(self, check_Q_spd=False):
+        mask = _lib.ST_Q_NOT_SPD | _lib.ST_A_RANK
         if self._pre_event is not None:
             self._pre_event.synchronize()
-            st = int(self._pre_host)
+            st = int(np.bitwise_or.reduce(self._pre_host.numpy())) & mask
         else:
-            st = int(self._pre_flag.item())
+            st = int(np.bitwise_or.reduce(self.status.cpu().numpy().reshape(-1))) & mask
         if st & _lib.ST_Q_NOT_SPD:
             if check_Q_spd:
                 raise RuntimeError('Q is not SPD.')
