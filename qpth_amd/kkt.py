@@ -84,7 +84,7 @@ class KKTFactors:
         nblob = 1 if self.shared else B
         self.sfac = 0 if self.shared else self.elems
         self.blob = torch.empty(nblob * self.elems, dtype=Q.dtype, device=Q.device)
-        self.status = torch.zeros(B, dtype=torch.int32, device=Q.device)
+        self.status = torch.empty(B, dtype=torch.int32, device=Q.device)      # every pre-factorisation kernel writes it
         self.lib.pre_factor(nblob, self.n, self.m, self.q, Q, G, A if self.q else None, self.blob, self.status)
         if self.shared:
             self.status[1:] = self.status[0]
@@ -138,7 +138,7 @@ a non-zero diagonal.
         r.nu = torch.empty(B, q, dtype=dt, device=dev)
         r.lam = torch.empty(B, m, dtype=dt, device=dev)
         r.slacks = torch.empty(B, m, dtype=dt, device=dev)
-        r.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        r.iters = torch.empty(B, dtype=torch.int32, device=dev)                # written on every path of the loop kernels
         r.best_resid = torch.empty(B, dtype=dt, device=dev)
         r.trace = torch.full((maxIter, B, 3), float('nan'), dtype=dt, device=dev) if want_trace else None
         r.status = self.status
