@@ -1,7 +1,11 @@
 #!/bin/bash
-OUT=gpurun_out/${1:-dbg5}; mkdir -p $OUT
+# A/B of the loop-kernel forms: QPX_VARIANT 0 = auto, 256 = 16x16 thread grid, 512 = 8x8, 1024 = matrix-core tiles
+OUT=gpurun_out/${1:-forms}; mkdir -p $OUT
+VARS=${VARS:-"1024 256"}
+if [ -z "$SKIP_TESTS" ]; then
 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -12 $OUT/pytest_gpu.log
-for v in 0 256; do
+fi
+for v in $VARS; do
 echo "== variant $v"
 QPX_VARIANT=$v timeout 300 python scripts/prof_phases.py 512 100 100 0 > $OUT/phases_c2_f64_v$v.log 2>&1; tail -9 $OUT/phases_c2_f64_v$v.log
 QPX_VARIANT=$v timeout 300 python scripts/prof_phases.py 4096 64 64 0 > $OUT/phases_c5_v$v.log 2>&1; tail -9 $OUT/phases_c5_v$v.log

@@ -299,3 +299,29 @@ def test_every_loop_kernel_form(dev, variant, shape):
     for mine, ref in zip(grads, grads_ref):
         if ref is not None and mine is not None:
             assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------- 5. the bench contract
+def test_bench_prints_one_json_line_with_the_contract_fields(dev):
+    """bench.py is what the driver times: one JSON line on stdout, the metric of BASELINE.json, the roofline
+    object of the dominant kernel.  (Short run, no CPU baseline.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=280, check=True).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"].startswith("QPs/sec (fwd+bwd) at batch=512 nz=100 nineq=100")
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1
