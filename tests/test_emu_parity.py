@@ -212,3 +212,23 @@ def test_every_loop_kernel_form(variant, shape):
     for mine, ref in zip(grads, grads_ref):
         if ref is not None and mine is not None:
             assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_against_the_oracle(seed):
+    """Odd sizes on purpose: every padding rule (tiles of 16, panels of 4, slots of 64), neq = 0 and > 0,
+    nineq smaller and larger than nz, one-QP and few-QP batches."""
+    rng = np.random.RandomState(1000 + seed)
+    B = int(rng.randint(1, 4))
+    n = int(rng.randint(1, 36))
+    m = int(rng.randint(1, 70))
+    q = int(rng.randint(0, min(n, 6) + 1)) if n > 1 else 0
+    arrs = problems.prof_qp(B, n, m, q, seed=seed)
+    dl = rng.randn(B, n)
+    per_qp_policy = 1 if B == 1 else 2             # the dispatcher's default (qpth_amd.kkt.default_stall_policy)
+    xr, _, _, _, grads_ref, _ = orc.qp_forward_backward(*arrs, dl, per_qp=True, stall_policy=per_qp_policy)
+    z, grads = run_qpf(arrs, dl)
+    assert rel_err(z, xr).max() < TOL, (B, n, m, q)
+    for mine, ref in zip(grads, grads_ref):
+        if ref is not None and mine is not None:
+            assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (B, n, m, q)
