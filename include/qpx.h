@@ -18,7 +18,8 @@
  *   - dtype: QPX_F32 or QPX_F64; every `void*` array below has that element type.
  *   - All pointers are DEVICE pointers valid on `stream` (a hipStream_t).  The caller owns every
  *     buffer; the library never allocates, frees or synchronises.  Calls are stream-ordered and
- *     re-entrant (no global state).
+ *     re-entrant (no global state apart from the A/B knob qpx_set_ipm_variant, which nothing
+ *     but measurements and tests should touch).
  *   - Arrays are dense, row-major, batch-major: Q (B,n,n), p (B,n), G (B,m,n), h (B,m),
  *     A (B,q,n), b (B,q).  A batch stride (in elements) of 0 means "one copy shared by the whole
  *     batch" (the reference's un-batched parameters, qpth/util.py:44-50).  q = 0: A, b unused.
