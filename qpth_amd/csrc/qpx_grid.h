@@ -631,8 +631,36 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
             const T mu = abs_(szdot / mT);
             const T pri = sqrt_(pri2);
             const T dual = tsz * F[lay.scal];      // || G^T 1 ||
+            const T feas = pri + dual, resid = feas + mT * mu;
+            // best iterate and the stop decision, BEFORE the factorisation (as batch.py:118-143 does): the
+            // pass that stops costs a mat-vec, not a factorisation
+            const T tau = sc[kTau];
+            T bres = sc[kBres];
+            int nnot = ctrl[kNnot], floor_hit = ctrl[kFloor];
+            int stopf = 0;
+            const bool better = (it == 0) || (resid < bres);
+            if (better) {
+                bres = resid; nnot = 0;
+                for (int i = lane; i < m; i += kWave) { vBZ[i] = vZ[i]; vBS[i] = vS[i]; }
+            } else if (a.stall_policy == 1 || (a.stall_policy == 2 && mT * mu < feas)) {
+                nnot += 1;
+            } else {
+                nnot = 0;
+            }
+            if (a.stall_policy == 2 && it >= 1 && feas > T(2) * (T(1) - sc[kAlphaPrev]) * sc[kFeasPrev]) floor_hit = 1;
+            if ((a.stall_policy != 0 && nnot >= a.notImprovedLim) || bres < a.eps || mu > T(1e32)) stopf = 1;
+            if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-2) * feas) stopf = 1;
+            const bool bad = !finite_(resid);
+            if (bad) stopf = 1;
+            b.wave_sync();           // every lane has read the scalars lane 0 is about to replace
             if (lane == 0) {
-                sc[kMu] = mu; sc[kSzdot] = szdot; sc[kFeas] = pri + dual; sc[kResid] = pri + dual + mT * mu;
+                sc[kMu] = mu; sc[kSzdot] = szdot;
+                ctrl[kIters] = it + 1;
+                if (better) { sc[kBres] = bres; sc[kBtau] = tau; }
+                sc[kFeasPrev] = feas;
+                ctrl[kNnot] = nnot; ctrl[kFloor] = floor_hit;
+                if (bad) ctrl[kSt] |= QPX_ST_NONFINITE;
+                ctrl[kStop] = stopf;
                 if (a.trace) {
                     T* tr = a.trace + ((size_t)it * a.B + qp) * 3;
                     tr[0] = pri; tr[1] = dual; tr[2] = mu;
@@ -640,53 +668,24 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
             }
         }
         Mat::sync(b);
+        stop = first ? 0 : ctrl[kStop];
+        if (stop) break;
         Mat::add_diag(g, E, vD);
         QPX_PROF(4)
         const bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
         QPX_PROF(5)
-        if (w0) {
-            int stopf = 0;
-            if (!ok) {
+        if (!ok) {                   // uniform: every wave computes the same pivots
+            if (w0) {
                 if (lane == 0) ctrl[kSt] |= QPX_ST_KKT_BREAKDOWN;
-                stopf = 1;
                 if (first) {
                     for (int i = lane; i < M8; i += kWave) {
                         if (i < m) { vBZ[i] = T(1); vBS[i] = T(1); }
                         vA[i] = T(0);
                     }
                 }
-            } else if (!first) {
-                const T resid = sc[kResid], feas = sc[kFeas], mu = sc[kMu], tau = sc[kTau];
-                T bres = sc[kBres];
-                int nnot = ctrl[kNnot], floor_hit = ctrl[kFloor];
-                const bool better = (it == 0) || (resid < bres);
-                if (better) {
-                    bres = resid; nnot = 0;
-                    for (int i = lane; i < m; i += kWave) { vBZ[i] = vZ[i]; vBS[i] = vS[i]; }
-                } else if (a.stall_policy == 1 || (a.stall_policy == 2 && mT * mu < feas)) {
-                    nnot += 1;
-                } else {
-                    nnot = 0;
-                }
-                if (a.stall_policy == 2 && it >= 1 && feas > T(2) * (T(1) - sc[kAlphaPrev]) * sc[kFeasPrev]) floor_hit = 1;
-                if ((a.stall_policy != 0 && nnot >= a.notImprovedLim) || bres < a.eps || mu > T(1e32)) stopf = 1;
-                if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-2) * feas) stopf = 1;
-                const bool bad = !finite_(resid);
-                if (bad) stopf = 1;
-                b.wave_sync();       // every lane has read the scalars lane 0 is about to replace
-                if (lane == 0) {
-                    ctrl[kIters] = it + 1;
-                    if (better) { sc[kBres] = bres; sc[kBtau] = tau; }
-                    sc[kFeasPrev] = feas;
-                    ctrl[kNnot] = nnot; ctrl[kFloor] = floor_hit;
-                    if (bad) ctrl[kSt] |= QPX_ST_NONFINITE;
-                }
             }
-            if (lane == 0) ctrl[kStop] = stopf;
+            break;
         }
-        Mat::sync(b);
-        stop = ctrl[kStop];
-        if (stop) break;
         // first pass: z_i = -T^-1 c; iterations: affine scaling direction dz_aff = -T^-1 (c + R z)
         QPX_PROF(1)
         Mat::solve_neg(b, g, E, rd, m, first ? vC : vRH, vX, vTm, scr);
