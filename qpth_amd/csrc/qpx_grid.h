@@ -274,16 +274,25 @@ template <class T, int MODE /*0: =, 1: +=, 2: -=*/>
 QPX_DEV void block_matTvec(const Block& blk, T* out, const T* Mat, const T* vec, int rows, int cols)
 {
     for (int c = blk.tid; c < cols; c += blk.nt) {
-        T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        // eight independent loads in flight per thread: the rows come from L2 / HBM (~800 ticks each way)
+        T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+        const T* col = Mat + c;
         int r = 0;
-        for (; r + 4 <= rows; r += 4) {
-            a0 = fma_(Mat[(size_t)r * cols + c], vec[r], a0);
-            a1 = fma_(Mat[(size_t)(r + 1) * cols + c], vec[r + 1], a1);
-            a2 = fma_(Mat[(size_t)(r + 2) * cols + c], vec[r + 2], a2);
-            a3 = fma_(Mat[(size_t)(r + 3) * cols + c], vec[r + 3], a3);
+        for (; r + 8 <= rows; r += 8) {
+            const T m0 = col[(size_t)r * cols], m1 = col[(size_t)(r + 1) * cols], m2 = col[(size_t)(r + 2) * cols];
+            const T m3 = col[(size_t)(r + 3) * cols], m4 = col[(size_t)(r + 4) * cols], m5 = col[(size_t)(r + 5) * cols];
+            const T m6 = col[(size_t)(r + 6) * cols], m7 = col[(size_t)(r + 7) * cols];
+            a0 = fma_(m0, vec[r], a0);
+            a1 = fma_(m1, vec[r + 1], a1);
+            a2 = fma_(m2, vec[r + 2], a2);
+            a3 = fma_(m3, vec[r + 3], a3);
+            a4 = fma_(m4, vec[r + 4], a4);
+            a5 = fma_(m5, vec[r + 5], a5);
+            a6 = fma_(m6, vec[r + 6], a6);
+            a7 = fma_(m7, vec[r + 7], a7);
         }
-        for (; r < rows; ++r) a0 = fma_(Mat[(size_t)r * cols + c], vec[r], a0);
-        const T sum = (a0 + a1) + (a2 + a3);
+        for (; r < rows; ++r) a0 = fma_(col[(size_t)r * cols], vec[r], a0);
+        const T sum = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
         out[c] = MODE == 0 ? sum : (MODE == 1 ? out[c] + sum : out[c] - sum);
     }
 }
