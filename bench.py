@@ -180,7 +180,7 @@ def main():
                     "launch_ms": t_ipm * 1e3}
 
         cpu_baseline = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported at N = 1 only
             from oracle import qp_oracle as orc
             ncpu = os.cpu_count() or 1
             np1 = np.ones((B, n), np_dt)
