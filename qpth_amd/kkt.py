@@ -131,6 +131,9 @@ a non-zero diagonal.
 
     # -- forward (batch.py:47-207) -------------------------------------------------------
     def ipm(self, p, h, b, eps=1e-12, maxIter=20, notImprovedLim=3, stall_policy=None, want_trace=False):
+        """The IPM loop (batch.py:47-207), one kernel launch, no host sync.  `result.status` IS the factors'
+        status array: the loop ORs its bits (breakdown, maxIter, inaccurate) into the pre-factorisation's,
+        so repeated calls on the same factors accumulate them."""
         B, n, m, q = self.B, self.n, self.m, self.q
         dt, dev = self.dtype, self.device
         r = IpmResult()

@@ -232,3 +232,23 @@ def test_random_shapes_against_the_oracle(seed):
     for mine, ref in zip(grads, grads_ref):
         if ref is not None and mine is not None:
             assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (B, n, m, q)
+
+
+def test_max_iter_and_eps_are_honoured():
+    """QPFunction(eps, maxIter) (qp.py:18-20): the loop stops on maxIter (status bit, best iterate returned)
+    and on best_resid < eps (batch.py:127-140) -- neither is exercised by the reference's own tests."""
+    from qpth_amd import _lib
+    from qpth_amd.kkt import KKTFactors
+    arrs = problems.prof_qp(3, 14, 11, 2, seed=4)
+    Q, p, G, h, A, b = tens(arrs, grad=False)
+    with emulated():
+        fac = KKTFactors.build(Q, G, A)
+        full = fac.ipm(p, h, b)
+        capped = fac.ipm(p, h, b, maxIter=3)
+        loose = fac.ipm(p, h, b, eps=1e-3)
+    assert int(capped.iters.max()) == 3
+    assert all(int(s) & _lib.ST_MAXITER for s in capped.status.tolist())
+    assert torch.isfinite(capped.zhat).all()
+    assert int(loose.iters.max()) < int(full.iters.min())
+    assert float(loose.best_resid.max()) < 1e-3
+    assert rel_err(loose.zhat.numpy(), full.zhat.numpy()).max() < 1e-2

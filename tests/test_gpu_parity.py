@@ -325,3 +325,23 @@ def test_bench_prints_one_json_line_with_the_contract_fields(dev):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
     assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1
+
+
+def test_max_iter_and_eps_are_honoured(dev):
+    """QPFunction(eps, maxIter) (qp.py:18-20): stop on maxIter (status bit, best iterate returned) and on
+    best_resid < eps (batch.py:127-140)."""
+    from qpth_amd import _lib
+    from qpth_amd.kkt import KKTFactors
+    arrs = problems.prof_qp(64, 100, 100, 0, seed=4)
+    Q, p, G, h, A, b = to_dev(arrs, dev, grad=False)
+    fac = KKTFactors.build(Q, G, A)
+    full = fac.ipm(p, h, b)
+    loose = fac.ipm(p, h, b, eps=1e-3)
+    capped = fac.ipm(p, h, b, maxIter=3)
+    torch.cuda.synchronize()
+    assert int(capped.iters.max()) == 3
+    assert all(int(s) & _lib.ST_MAXITER for s in capped.status.tolist())
+    assert torch.isfinite(capped.zhat).all()
+    assert int(loose.iters.max()) < int(full.iters.min())
+    assert float(loose.best_resid.max()) < 1e-3
+    assert rel_err(loose.zhat.cpu().numpy(), full.zhat.cpu().numpy()).max() < 1e-2
