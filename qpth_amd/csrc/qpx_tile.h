@@ -233,13 +233,15 @@ template <int NBL, int NW> struct TileMat {
         T* S = scr + kS + (SP & 1) * 16;
         const bool inpan = (p.c >> 2) == SP;
         const int kc = p.c & 3;
-        // -- publish: the panel's four rows left of the panel ...
+        // -- publish: the panel's four rows left of the panel (in the panel's own tile only the columns
+        // left of it: the identity and the columns below are written by other lanes further down, and two
+        // lanes must not write one address even if a GPU wave would order them) ...
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
             if (p.row(pp) != Ip) continue;
 #pragma unroll
             for (int J = 0; J < psize(pp); ++J)
-                if (J <= Ip) X[p.g * MP + 16 * J + p.c] = E.e[slot(pp, J)][SP];
+                if (J < Ip || (J == Ip && p.c < 4 * SP)) X[p.g * MP + 16 * J + p.c] = E.e[slot(pp, J)][SP];
         }
         // ... the pivot block (identity in X, the block itself in S) and the four columns below it.
         // Row g + 4 r of tile row I lies below the panel iff I > Ip or r > SP.  The panel's own columns

@@ -1,0 +1,75 @@
+// tests/emu/tsan_driver.cpp -- runs the kernel bodies (host-thread emulation) under ThreadSanitizer.
+// TEST INFRASTRUCTURE ONLY.  One pthread per GPU thread means every LDS exchange that is not ordered by
+// a barrier (__syncthreads / wave-level ordering point) shows up as a data race -- including the ones
+// a GPU would hide by executing a wave in lock step.  Usage: tsan_driver <B> <n> <m> <q> [variant]
+// Exit code 0 and no "WARNING: ThreadSanitizer" on stderr = clean.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/qpx.h"
+
+static double urand(unsigned& s)
+{
+    s = s * 1664525u + 1013904223u;
+    return (double)(s >> 8) / (double)(1u << 24);
+}
+
+int main(int argc, char** argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 1, n = argc > 2 ? atoi(argv[2]) : 20, m = argc > 3 ? atoi(argv[3]) : 24;
+    const int q = argc > 4 ? atoi(argv[4]) : 3;
+    if (argc > 5) qpx_set_ipm_variant(atoi(argv[5]));
+    unsigned seed = 12345;
+    std::vector<double> Q((size_t)B * n * n), p((size_t)B * n), G((size_t)B * m * n), h((size_t)B * m);
+    std::vector<double> A((size_t)B * q * n + 1), bb((size_t)B * q + 1);
+    for (int s = 0; s < B; ++s) {
+        std::vector<double> L((size_t)n * n);
+        for (auto& v : L) v = urand(seed) - 0.5;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double acc = (i == j) ? 1e-3 : 0.0;
+                for (int k = 0; k < n; ++k) acc += L[(size_t)i * n + k] * L[(size_t)j * n + k];
+                Q[((size_t)s * n + i) * n + j] = acc;
+            }
+        std::vector<double> z0(n);
+        for (int i = 0; i < n; ++i) { p[(size_t)s * n + i] = urand(seed) - 0.5; z0[i] = urand(seed) - 0.5; }
+        for (int i = 0; i < m; ++i) {
+            double acc = 0;
+            for (int j = 0; j < n; ++j) { const double g = urand(seed) - 0.5; G[((size_t)s * m + i) * n + j] = g; acc += g * z0[j]; }
+            h[(size_t)s * m + i] = acc + urand(seed);                 // feasible: h = G z0 + s0, s0 > 0
+        }
+        for (int i = 0; i < q; ++i) {
+            double acc = 0;
+            for (int j = 0; j < n; ++j) { const double a = urand(seed) - 0.5; A[((size_t)s * q + i) * n + j] = a; acc += a * z0[j]; }
+            bb[(size_t)s * q + i] = acc;
+        }
+    }
+    const size_t fe = qpx_factor_elems(n, m, q);
+    std::vector<double> fac((size_t)B * fe), zhat((size_t)B * n), nu((size_t)B * q + 1), lam((size_t)B * m), sl((size_t)B * m), br(B);
+    std::vector<int32_t> status(B), iters(B);
+    int rc = qpx_pre_factor(QPX_F64, B, n, m, q, Q.data(), (int64_t)n * n, G.data(), (int64_t)m * n, q ? A.data() : nullptr,
+                            (int64_t)q * n, fac.data(), status.data(), nullptr);
+    if (rc) { fprintf(stderr, "pre_factor rc %d\n", rc); return 2; }
+    rc = qpx_ipm(QPX_F64, B, n, m, q, p.data(), n, h.data(), m, q ? bb.data() : nullptr, q, fac.data(), (int64_t)fe, 1e-12, 20, 3,
+                 B == 1 ? 1 : 2, zhat.data(), q ? nu.data() : nullptr, lam.data(), sl.data(), iters.data(), status.data(), br.data(),
+                 nullptr, nullptr);
+    if (rc) { fprintf(stderr, "ipm rc %d\n", rc); return 2; }
+    std::vector<double> g((size_t)B * n, 1.0), dQ((size_t)B * n * n), dp((size_t)B * n), dG((size_t)B * m * n), dh((size_t)B * m);
+    std::vector<double> dA((size_t)B * q * n + 1), db((size_t)B * q + 1);
+    rc = qpx_backward(QPX_F64, B, n, m, q, fac.data(), (int64_t)fe, zhat.data(), lam.data(), sl.data(), q ? nu.data() : nullptr, g.data(),
+                      dQ.data(), dp.data(), dG.data(), dh.data(), q ? dA.data() : nullptr, q ? db.data() : nullptr, status.data(), nullptr);
+    if (rc) { fprintf(stderr, "backward rc %d\n", rc); return 2; }
+    double worst = 0;
+    for (int s = 0; s < B; ++s) {
+        for (int i = 0; i < m; ++i) {                               // primal feasibility G z <= h
+            double acc = -h[(size_t)s * m + i];
+            for (int j = 0; j < n; ++j) acc += G[((size_t)s * m + i) * n + j] * zhat[(size_t)s * n + j];
+            worst = std::fmax(worst, acc);
+        }
+        printf("qp %d: iters %d status %d best_resid %.2e\n", s, iters[s], status[s], br[s]);
+    }
+    printf("max constraint violation %.2e\n", worst);
+    return worst < 1e-6 ? 0 : 1;
+}

@@ -252,3 +252,14 @@ def test_max_iter_and_eps_are_honoured():
     assert int(loose.iters.max()) < int(full.iters.min())
     assert float(loose.best_resid.max()) < 1e-3
     assert rel_err(loose.zhat.numpy(), full.zhat.numpy()).max() < 1e-2
+
+
+@pytest.mark.skipif(bool(__import__("os").environ.get("QPX_SKIP_TSAN")), reason="QPX_SKIP_TSAN set")
+def test_kernel_bodies_are_race_free_under_thread_sanitizer():
+    """`make -C tests/emu tsan`: every kernel family on host threads under ThreadSanitizer.  It found a real
+    write-write overlap in the tile panel's publish (two lanes of one wave, ordered only by the GPU's in-order
+    LDS pipeline) that the plain emulator runs never tripped over."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    subprocess.check_call(["make", "-C", here, "-s", "tsan"], timeout=900)     # ~95 s to build, ~35 s to run
