@@ -17,6 +17,12 @@
 #include "qpx_grid.h"
 #include "qpx_tile.h"
 
+// Extra bytes behind the emulated LDS block.  The sanitizer build uses 0 so that an index one element past
+// the size the launcher computed is already a reported overflow.
+#ifndef QPX_EMU_LDS_SLACK
+#define QPX_EMU_LDS_SLACK 64
+#endif
+
 namespace qpx {
 
 template <int V> using Int = std::integral_constant<int, V>;
@@ -84,7 +90,7 @@ int launch_prefactor(const PrefactorArgs<T>& a, size_t lds_bytes, void*)
 {
     const int nt = emu_threads();
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(nt, [&](const Block& b) { prefactor_body<T, NS, kLds>(b, a, qp, base); });
     }
@@ -96,7 +102,7 @@ int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void*)
 {
     const int nt = emu_threads();
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(nt, [&](const Block& b) { ipm_body<T, NS, kLds>(b, a, qp, base); });
     }
@@ -108,7 +114,7 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void*)
 {
     const int nt = emu_threads();
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(nt, [&](const Block& b) { kkt_body<T, NS, kLds, kBw>(b, a, qp, base); });
     }
@@ -119,7 +125,7 @@ template <class T, int NB, int NS>
 int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(kWave, [&](const Block& b) { ipm_wave_body<T, NB, NS>(b, a, qp, base); });
     }
@@ -129,7 +135,7 @@ int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void*)
 template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(256, [&](const Block& b) { sweep_body<T, NBL>(b, a, qp, base); });
     }
@@ -138,7 +144,7 @@ template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t l
 template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(256, [&](const Block& b) { ipm_grid_body<T, 16, NBL, NS>(b, a, qp, base); });
     }
@@ -147,7 +153,7 @@ template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, siz
 template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(64, [&](const Block& b) { ipm_grid_body<T, 8, NBL, NS>(b, a, qp, base); });
     }
@@ -156,7 +162,7 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
 template <int NBL, int NW, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         double* base = reinterpret_cast<double*>(lds.data());
         run_block(64 * NW, [&](const Block& b) { ipm_tile_body<NBL, NW, NS>(b, a, qp, base); });
     }
@@ -165,7 +171,7 @@ template <int NBL, int NW, int NS> int launch_ipm_tile(const IpmArgs<double>& a,
 template <int NBL, int NW> int launch_prefactor_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         double* base = reinterpret_cast<double*>(lds.data());
         run_block(64 * NW, [&](const Block& b) { prefactor_tile_body<NBL, NW>(b, a, qp, base); });
     }
@@ -174,7 +180,7 @@ template <int NBL, int NW> int launch_prefactor_tile(const PrefactorArgs<double>
 template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         double* base = reinterpret_cast<double*>(lds.data());
         run_block(64 * NW, [&](const Block& b) { kkt_tile_body<NBL, NW, kBw>(b, a, qp, base); });
     }
@@ -183,7 +189,7 @@ template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& 
 template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + 64);
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(256, [&](const Block& b) { kkt_grid_body<T, 16, NBL, kBw>(b, a, qp, base); });
     }
