@@ -1,0 +1,62 @@
+"""Host-side logic above the C ABI (no kernels run): the helpers that mirror qpth/util.py, the batch
+sharding arithmetic, the loud refusal of CPU tensors, argument checking of the factor object."""
+import pytest
+import torch
+
+from qpth_amd import _lib, dist, util
+from qpth_amd.kkt import KKTFactors, default_stall_policy
+from qpth_amd.qp import QPFunction
+
+
+def test_util_helpers_follow_the_reference():
+    x, y = torch.randn(3, 4), torch.randn(3, 5)
+    assert torch.allclose(util.bger(x, y), torch.einsum("bi,bj->bij", x, y))            # util.py:18-19
+    G, A = torch.zeros(7, 6, 5), torch.zeros(7, 2, 5)
+    assert util.get_sizes(G, A) == (6, 5, 2, 7)                                           # util.py:22-33
+    assert util.get_sizes(G[0], torch.empty(0)) == (6, 5, 0, 1)
+    d = torch.randn(2, 3)
+    assert torch.equal(util.bdiag(d)[1], torch.diag(d[1]))                                # util.py:36-41
+    p = torch.randn(5)
+    pe, expanded = util.expandParam(p, 7, 2)                                              # util.py:44-50
+    assert expanded and pe.shape == (7, 5) and pe.stride(0) == 0
+    assert util.expandParam(torch.randn(7, 5), 7, 2)[1] is False
+    assert util.expandParam(torch.empty(0), 7, 2)[1] is False
+    with pytest.raises(RuntimeError, match="Unexpected number of dimensions"):
+        util.expandParam(torch.randn(2, 3, 4, 5), 7, 2)
+    e = torch.empty(0)
+    assert util.extract_nBatch(torch.randn(5, 5), torch.randn(9, 5), G[0], torch.randn(6), e, e) == 9   # util.py:53-59
+    assert util.extract_nBatch(torch.randn(5, 5), torch.randn(5), G[0], torch.randn(6), e, e) == 1
+
+
+@pytest.mark.parametrize("nBatch,world", [(512, 8), (65536, 8), (5, 2), (3, 4), (1, 8)])
+def test_shards_partition_the_batch(nBatch, world):
+    bounds = [dist.shard_bounds(nBatch, r, world) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == nBatch
+    assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+    sizes = [hi - lo for lo, hi in bounds]
+    assert max(sizes) - min(sizes) <= 1
+    full = torch.arange(nBatch * 2.0).reshape(nBatch, 2)
+    shared = torch.randn(2)
+    parts = [dist.shard_params([shared, full, shared, full, torch.empty(0), torch.empty(0)], nBatch, r, world,
+                               ndims=(2, 2, 2, 2, 3, 2)) for r in range(world)]
+    assert torch.equal(torch.cat([p[1] for p in parts]), full)
+    assert all(p[0] is shared for p in parts)
+
+
+def test_cpu_tensors_are_refused_loudly():
+    """There is no CPU path in the product: the error must say so (the emulator is installed by tests only)."""
+    assert _lib._TEST_BACKEND is None
+    Q = torch.eye(3, dtype=torch.float64).unsqueeze(0)
+    G, h, p = torch.ones(1, 2, 3, dtype=torch.float64), torch.ones(1, 2, dtype=torch.float64), torch.ones(1, 3, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        QPFunction(verbose=-1)(Q, p, G, h, torch.empty(0, dtype=torch.float64), torch.empty(0, dtype=torch.float64))
+
+
+def test_inconsistent_sizes_are_an_error_before_any_launch():
+    Q, G = torch.eye(3).unsqueeze(0), torch.ones(1, 2, 4)
+    with pytest.raises(RuntimeError, match="inconsistent QP sizes"):
+        KKTFactors.build(Q, G, torch.empty(0))
+
+
+def test_default_stall_policy_is_the_reference_counter_for_one_qp():
+    assert default_stall_policy(1) == _lib.STALL_REFERENCE and default_stall_policy(2) == _lib.STALL_FLOOR
