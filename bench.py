@@ -43,24 +43,16 @@ HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 MFMA_PEAK = {"f64": 78.6e12, "f32": 157.3e12}
 
 
-def algorithmic_flops_per_qp(n, m, q, passes):
-    """flops the loop kernel's algorithm needs per QP.  `passes` = IPM iterations + 1
-    (the start point is one more factorisation + solve).  Per pass: the factorisation with in-place
-    inverse factor, m^3/3 multiply-adds; two solves of two triangular mat-vecs, 2 m^2; one symmetric
-    mat-vec, m^2.  Once: c = h + M p, zhat = -K p - M^T z' (and the neq terms)."""
-    per_pass = 2.0 * (m ** 3 / 3.0 + 3.0 * m * m)
-    once = 2.0 * (2.0 * m * n + n * n + 2.0 * q * (n + m + q))
-    return passes * per_pass + once
-
-
-
-def algorithmic_bytes_per_qp(n, m, q, w):
-    """compulsory HBM traffic per QP (forward read+write, backward read+write)."""
-    fwd_r = w * (n * n + m * n + q * n + n + m + q)
-    fwd_w = w * (n + 2 * m + q)
-    bwd_r = w * (n * n + m * n + q * n + 2 * n + 2 * m + q)
-    bwd_w = w * (n * n + n + m * n + m + q * n + q)
-    return fwd_r, fwd_w, bwd_r, bwd_w
+def algorithmic_flops_per_qp(n, m, q, iters):
+    """SURVEY.md section 8(d), "ALGORITHMIC flops per QP (Cholesky-minimum)", the part the loop kernel
+    replaces: per IPM iteration m^3/3 (factor) + 2 x (4n^2 + 4mn + 4qn + 2m^2) (two solves) + 2n^2 + 4mn + 4qn
+    (residuals); the start point is one more factorisation + solve.  (The kernel itself spends 2x the
+    factorisation flops -- it builds the inverse factor in place -- and far fewer on solves and residuals,
+    which it does in the m-dimensional condensed space; the roofline prices the algorithm, not the kernel.)"""
+    solve = 4.0 * n * n + 4.0 * m * n + 4.0 * q * n + 2.0 * m * m
+    resid = 2.0 * n * n + 4.0 * m * n + 4.0 * q * n
+    fact = m ** 3 / 3.0
+    return iters * (fact + 2.0 * solve + resid) + (fact + solve)
 
 
 def main():
@@ -161,7 +153,7 @@ def main():
         ipm_bytes = (fwd_r + fwd_w) * B          # the forward's compulsory traffic, DESIGN.md section 6
         # The loop kernel is compute-side bound (55 flop per compulsory byte at C2, machine balance ~10):
         # its roofline is the dense matrix/vector peak of the dtype it computes in.
-        ipm_flops = algorithmic_flops_per_qp(n, m, q, iters_mean + 1.0) * B
+        ipm_flops = algorithmic_flops_per_qp(n, m, q, iters_mean) * B
         achieved = ipm_flops / t_ipm
         peak = MFMA_PEAK[args.dtype]
         traffic = None
