@@ -55,6 +55,15 @@ def algorithmic_flops_per_qp(n, m, q, iters):
     return iters * (fact + 2.0 * solve + resid) + (fact + solve)
 
 
+def algorithmic_bytes_per_qp(n, m, q, w):
+    """compulsory HBM traffic per QP (forward read+write, backward read+write)."""
+    fwd_r = w * (n * n + m * n + q * n + n + m + q)
+    fwd_w = w * (n + 2 * m + q)
+    bwd_r = w * (n * n + m * n + q * n + 2 * n + 2 * m + q)
+    bwd_w = w * (n * n + n + m * n + m + q * n + q)
+    return fwd_r, fwd_w, bwd_r, bwd_w
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
