@@ -159,5 +159,24 @@ def main():
     save("unbatched_n12_m9_q3", Q=Qs, p=p[0], G=Gs, h=hs[0], A=As, b=bs[0], **o)
 
 
+def extra():
+    """Edge shapes added after the first fixture set (run with --extra; leaves the other files alone):
+    one variable / one constraint, neq = nz - 1 (one degree of freedom left), duplicated inequality rows
+    (R + D^-1 is still SPD, R itself is rank deficient)."""
+    def case(name, arrs):
+        Q, p, G, h, A, b = arrs
+        o = run_ref(Q, p, G, h, A, b, dl=lambda z: np.ones_like(z))
+        o.update(run_ref_b1(Q, p, G, h, A, b))
+        save(name, Q=Q, p=p, G=G, h=h, A=A, b=b, **o)
+
+    case("edge_b3_n1_m1_q0", problems.prof_qp(3, 1, 1, 0, 5))
+    case("edge_b2_n6_m4_q5", problems.prof_qp(2, 6, 4, 5, 6))
+    Q, p, G, h, A, b = problems.prof_qp(2, 8, 5, 0, 7)
+    case("edge_dup_b2_n8_m10_q0", (Q, p, np.concatenate([G, G], 1), np.concatenate([h, h], 1), A, b))
+
+
 if __name__ == "__main__":
-    main()
+    if "--extra" in sys.argv:
+        extra()
+    else:
+        main()

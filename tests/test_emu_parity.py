@@ -263,3 +263,17 @@ def test_kernel_bodies_are_race_free_under_thread_sanitizer():
     import subprocess
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
     subprocess.check_call(["make", "-C", here, "-s", "tsan"], timeout=900)     # ~95 s to build, ~35 s to run
+
+
+@pytest.mark.parametrize("name", ["edge_b3_n1_m1_q0", "edge_b2_n6_m4_q5", "edge_dup_b2_n8_m10_q0"])
+def test_edge_shapes_match_the_reference(name):
+    """One variable / one constraint; neq = nz - 1; duplicated inequality rows (their multipliers and the
+    gradients with respect to the duplicated rows are not unique: only z*, slacks and the other gradients
+    are compared there)."""
+    g = load_golden(name)
+    arrs = [g[k] for k in ("Q", "p", "G", "h", "A", "b")]
+    z, grads = run_qpf(arrs, g["dl_dz"])
+    assert rel_err(z, g["zhat"]).max() < TOL
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g and gr is not None and not ("dup" in name and k in ("dG", "dh")):
+            assert np.abs(gr - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k

@@ -345,3 +345,17 @@ def test_max_iter_and_eps_are_honoured(dev):
     assert int(loose.iters.max()) < int(full.iters.min())
     assert float(loose.best_resid.max()) < 1e-3
     assert rel_err(loose.zhat.cpu().numpy(), full.zhat.cpu().numpy()).max() < 1e-2
+
+
+@pytest.mark.parametrize("name", ["edge_b3_n1_m1_q0", "edge_b2_n6_m4_q5", "edge_dup_b2_n8_m10_q0"])
+def test_edge_shapes_match_the_reference(dev, name):
+    """One variable / one constraint; neq = nz - 1; duplicated inequality rows (their multipliers and the
+    gradients with respect to the duplicated rows are not unique: only z*, slacks and the other gradients
+    are compared there)."""
+    g = load_golden(name)
+    arrs = [g[k] for k in ("Q", "p", "G", "h", "A", "b")]
+    z, grads = run_qpf(arrs, g["dl_dz"], dev)
+    assert rel_err(z, g["zhat"]).max() < TOL
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g and gr is not None and not ("dup" in name and k in ("dG", "dh")):
+            assert np.abs(gr - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k

@@ -100,3 +100,22 @@ def orc_checksum(*arrs):
     return np.array([float(np.sum(np.asarray(a, np.float64) *
                                   np.cos(np.arange(np.asarray(a).size).reshape(np.shape(a)) % 97)))
                      for a in arrs if np.asarray(a).size])
+
+
+EDGE = ["edge_b3_n1_m1_q0", "edge_b2_n6_m4_q5", "edge_dup_b2_n8_m10_q0"]
+
+
+@pytest.mark.parametrize("name", EDGE)
+def test_edge_shapes(name):
+    """One variable / one constraint; neq = nz - 1; duplicated inequality rows -- against the reference run on
+    the same inputs (tests/golden/make_golden.py --extra)."""
+    g = load_golden(name)
+    Q, p, G, h, A, b = [g[k] for k in ("Q", "p", "G", "h", "A", "b")]
+    x, y, z, s, grads, info = orc.qp_forward_backward(Q, p, G, h, A, b, dl_dz=g["dl_dz"])
+    assert rel_err(x, g["zhat"]).max() < F64_TOL
+    assert np.abs(s - g["slacks"]).max() < 1e-6
+    if "dup" not in name:                  # duplicated rows: the multipliers of a duplicated pair are not unique
+        assert np.abs(z - g["lam"]).max() < 1e-6
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g and not ("dup" in name and k in ("dG", "dh")):
+            assert np.abs(gr - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
