@@ -18,15 +18,15 @@
  *   - dtype: QPX_F32 or QPX_F64; every `void*` array below has that element type.
  *   - All pointers are DEVICE pointers valid on `stream` (a hipStream_t).  The caller owns every
  *     buffer; the library never allocates, frees or synchronises.  Calls are stream-ordered and
- *     re-entrant (no global state apart from the A/B knob qpx_set_ipm_variant, which nothing
- *     but measurements and tests should touch).
+ *     re-entrant: the only mutable state is the A/B knob of qpx_set_ipm_variant, which is per host
+ *     thread (thread_local) and which nothing but measurements and tests should touch.
  *   - Arrays are dense, row-major, batch-major: Q (B,n,n), p (B,n), G (B,m,n), h (B,m),
  *     A (B,q,n), b (B,q).  A batch stride (in elements) of 0 means "one copy shared by the whole
  *     batch" (the reference's un-batched parameters, qpth/util.py:44-50).  q = 0: A, b unused.
- *   - `factors`: B * qpx_factor_elems(n,m,q) elements of scratch that carries the
+ *   - `factors`: B * qpx_factor_elems(dtype,n,m,q) elements of scratch that carries the
  *     factorisations from qpx_pre_factor to qpx_ipm / qpx_factor_solve_kkt / qpx_backward
  *     (what the reference stashes on ctx as Q_LU, S_LU, R; qpth/qp.py:93).  Consumers take
- *     its batch stride `sfac` in elements: qpx_factor_elems(n,m,q), or 0 when Q, G, A are
+ *     its batch stride `sfac` in elements: qpx_factor_elems(dtype,n,m,q), or 0 when Q, G, A are
  *     shared by the whole batch and were factored once with B = 1 (only if qpx_fits_lds()).
  *   - `status`: int32[B], per-QP bit mask of QPX_ST_* written on the device; the functions
  *     themselves return 0 or a negative QPX_ERR_* launch/argument error and never throw.
@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define QPX_ABI_VERSION 1
+#define QPX_ABI_VERSION 2
 
 enum { QPX_F32 = 0, QPX_F64 = 1 };
 
@@ -75,23 +75,23 @@ typedef void* qpx_stream_t; /* hipStream_t */
 int qpx_abi_version(void);
 const char* qpx_strerror(int code);
 
-/* elements (of dtype) of factor storage per QP */
-size_t qpx_factor_elems(int n, int m, int q);
+/* elements (of dtype) of factor storage per QP (C2, f64: 27 100 = 217 KB; B = 65536, n = m = 64: 5.5 GB) */
+size_t qpx_factor_elems(int dtype, int n, int m, int q);
 
 /* largest max(n,m,q) this build can solve; whether (n,m,q) runs with LDS-resident matrices */
 int qpx_max_dim(void);
 int qpx_fits_lds(int dtype, int n, int m, int q);
 
-/* tuning/A-B knob: which kernel family runs.  0 (default) = automatic: the 16x16 thread-grid
- * kernels (sweep pre-factorisation, register-resident LDL^T with in-place inverse factor)
+/* tuning/A-B knob (per host thread): which kernel family runs.  0 (default) = automatic: the thread-grid /
+ * matrix-core kernels (sweep pre-factorisation, register-resident LDL^T with in-place inverse factor)
  * whenever nz+neq+nineq <= 208, else one 256-thread workgroup per QP with the matrices in LDS
- * (or in HBM when they do not fit); 1 = always the workgroup kernels; 2 = workgroup
- * pre-factorisation/backward + the one-wave-per-QP loop (nineq <= 104, nz <= 128).
+ * (or in HBM when they do not fit); 1 = always the workgroup kernels.
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4, adding 16384 selects the (slower, experimental) tile pre-factorisation instead of the
  * thread-grid sweep; by default the library picks by dtype, size and batch.
- * The knob must not change between qpx_pre_factor and the calls that consume its factors.
+ * The knob must not change between qpx_pre_factor and the calls that consume its factors (it selects the
+ * layout of `factors` too: ask qpx_factor_elems after setting it).
  * Returns the previous value. */
 int qpx_set_ipm_variant(int variant);
 
@@ -127,12 +127,22 @@ int qpx_factor_solve_kkt(int dtype, int B, int n, int m, int q, void* factors, i
 
 /* QPFunctionFn.backward for given (zhat, lam, slacks, nu) -- from qpx_ipm or from any other
  * solver (qp.py:142-155) -- and dl_dz (B,n).  Per-QP gradients dQ (B,n,n), dp (B,n),
- * dG (B,m,n), dh (B,m), dA (B,q,n), db (B,q); mean-reduction over a broadcast batch
- * (qp.py:159-177) is the caller's. */
+ * dG (B,m,n), dh (B,m), dA (B,q,n), db (B,q); each of the six may be NULL = "this gradient is not
+ * wanted" (ctx.needs_input_grad): nothing is computed or written for it.  dx (B,n), dz (B,m),
+ * dy (B,q): optional (NULL = skip) solution of the backward KKT system itself (qp.py:151-155), the
+ * inputs of qpx_batch_outer. */
 int qpx_backward(int dtype, int B, int n, int m, int q, void* factors, int64_t sfac,
                  const void* zhat, const void* lam, const void* slack, const void* nu, const void* dl_dz,
                  void* dQ, void* dp, void* dG, void* dh, void* dA, void* db,
-                 int32_t* status, qpx_stream_t stream);
+                 void* dx, void* dz, void* dy, int32_t* status, qpx_stream_t stream);
+
+/* Batch-MEAN of the gradient of a parameter that the whole batch shares (qp.py:159-177: the reference
+ * forms B outer products and then `.mean(0)`): one contraction over the batch instead,
+ *   out (r,c) = scale/B * sum_b ( u[b][r] v[b][c] + w[b][r] x[b][c] )        u, w: (B,r)  v, x: (B,c)
+ * dQ: u = dx, v = zhat, w = zhat, x = dx, scale = 0.5;  dG: u = dz, v = zhat, w = lam, x = dx, scale = 1;
+ * dA: u = dy, v = zhat, w = nu, x = dx.  `out` is (r,c) of dtype, overwritten. */
+int qpx_batch_outer(int dtype, int B, int r, int c, const void* u, const void* v, const void* w,
+                    const void* x, double scale, void* out, qpx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)       -- must list every symbol include/qpx.h declares
     "qpx_abi_version": (_i, []),
     "qpx_strerror": (ctypes.c_char_p, [_i]),
-    "qpx_factor_elems": (ctypes.c_size_t, [_i, _i, _i]),
+    "qpx_factor_elems": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "qpx_max_dim": (_i, []),
     "qpx_fits_lds": (_i, [_i, _i, _i, _i]),
     "qpx_set_ipm_variant": (_i, [_i]),
@@ -39,7 +39,8 @@ _SIGNATURES = {
     "qpx_factor_solve_kkt": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp]),
     "qpx_backward": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                          _vp, _vp, _vp]),
+                          _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qpx_batch_outer": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp]),
 }
 ABI_SYMBOLS = tuple(_SIGNATURES)
 
@@ -95,15 +96,15 @@ class QpxLib:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(self.dll, name)       # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if self.dll.qpx_abi_version() != 1:
+        if self.dll.qpx_abi_version() != 2:
             raise RuntimeError("qpth_amd: ABI version mismatch in %s" % path)
 
     def check(self, code):
         if code != 0:
             raise RuntimeError("qpth_amd: %s (code %d)" % (self.dll.qpx_strerror(code).decode(), code))
 
-    def factor_elems(self, n, m, q):
-        return int(self.dll.qpx_factor_elems(n, m, q))
+    def factor_elems(self, dtype_code, n, m, q):
+        return int(self.dll.qpx_factor_elems(dtype_code, n, m, q))
 
     # -- batch.py:375-429 ---------------------------------------------------------------
     def pre_factor(self, B, n, m, q, Q, G, A, factors, status):
@@ -140,11 +141,20 @@ class QpxLib:
             _ptr(ry), _ptr(dx), _ptr(ds), _ptr(dz), _ptr(dy), _ptr(status), _stream(factors)))
 
     # -- qp.py:127-182 --------------------------------------------------------------------
-    def backward(self, B, n, m, q, factors, sfac, zhat, lam, slack, nu, dl_dz, dQ, dp, dG, dh, dA, db, status):
+    def backward(self, B, n, m, q, factors, sfac, zhat, lam, slack, nu, dl_dz, dQ, dp, dG, dh, dA, db, status,
+                 dx=None, dz=None, dy=None):
+        """Any of dQ..db may be None (gradient not wanted); dx, dz, dy: optional KKT solution outputs."""
         self.check(self.dll.qpx_backward(
             _dtype_code(factors), B, n, m, q, _ptr(factors), int(sfac), _ptr(zhat), _ptr(lam), _ptr(slack),
             _ptr(nu), _ptr(dl_dz), _ptr(dQ), _ptr(dp), _ptr(dG), _ptr(dh), _ptr(dA), _ptr(db),
-            _ptr(status), _stream(factors)))
+            _ptr(dx), _ptr(dz), _ptr(dy), _ptr(status), _stream(factors)))
+
+    # -- qp.py:159-177, the `.mean(0)` of a shared parameter's gradient as one contraction over the batch
+    def batch_outer(self, u, v, w, x, scale, out):
+        B, r = u.shape
+        c = v.shape[1]
+        self.check(self.dll.qpx_batch_outer(_dtype_code(out), B, r, c, _ptr(u), _ptr(v), _ptr(w), _ptr(x),
+                                            float(scale), _ptr(out), _stream(out)))
 
 
 _HIP = None

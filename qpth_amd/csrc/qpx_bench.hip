@@ -1,4 +1,4 @@
-// qpx_bench.hip -- micro-benchmarks of the gfx950 primitives the wave-per-QP kernel is built from
+// qpx_bench.hip -- micro-benchmarks of the gfx950 primitives the kernels are built from
 // (NOT part of libqpx_hip.so; built as libqpx_bench.so by `make bench`, driven by scripts/ubench.py).
 // Every kernel runs single-wave workgroups and reports shader-clock cycles (clock64) per
 // operation for wave 0 of every block.
@@ -6,7 +6,7 @@
 
 #include <cstdint>
 
-#include "qpx_wave.h"
+#include "qpx_kernels.h"
 
 using namespace qpx;
 
@@ -137,39 +137,6 @@ BENCH_KERNEL(k_bpermute)
     if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (6.0 * reps);
 }
 
-// 8. the real routines: register-resident LDL^T and the two substitutions, NB = 13 / 8
-template <int NB, int MODE> __global__ __launch_bounds__(64) void k_ldl(double* out, const double* Rw, int reps, int m)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* Lc = reinterpret_cast<double*>(smem);
-    double* rd = Lc + (8 * NB) * (8 * NB + 1) / 2 + 8;
-    const Block b{(int)threadIdx.x, 64};
-    const double* mine = Rw + (size_t)blockIdx.x * wave_tri(NB) * 64;
-    double Tr[wave_tri(NB)];
-    long long tl = 0, tf = 0, ts = 0;
-    bool ok = true;
-    double acc = 0;
-    for (int r = 0; r < reps; ++r) {
-        wave_load_R<double, NB>(b, Tr, mine);
-        long long t0 = clock64();
-        ok = wave_ldl<double, NB>(b, Tr, Lc, rd, m) && ok;
-        long long t1 = clock64();
-        double x[2] = {1.0 + threadIdx.x, 2.0};
-        if (MODE >= 1) wtrsv_fwd<2>(b, Lc, rd, 8 * NB, m, x);
-        long long t2 = clock64();
-        if (MODE >= 1) wtrsv_bwd<2>(b, Lc, rd, 8 * NB, m, x);
-        long long t3 = clock64();
-        tl += t1 - t0; tf += t2 - t1; ts += t3 - t2;
-        acc += x[0] + x[1];
-    }
-    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = acc + (ok ? 0.0 : 1e300);
-    if (threadIdx.x == 0) {
-        out[4096 + blockIdx.x] = double(tl) / reps;
-        out[8192 + blockIdx.x] = double(tf) / reps;
-        out[12288 + blockIdx.x] = double(ts) / reps;
-    }
-}
-
 // 10. v_mfma_f64_16x16x4_f64: NACC independent accumulators issued round-robin (throughput at
 // NACC = 8, dependent-chain latency at NACC = 1); and the same rank-4 update of a 16x16 tile done
 // with 16 vector FMAs per lane (operands in registers) for comparison
@@ -252,18 +219,6 @@ extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, co
     case 21: hipLaunchKernelGGL(k_mfma_f64<1>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 22: hipLaunchKernelGGL(k_mfma_f64<2>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 23: hipLaunchKernelGGL(k_vfma_tile<8>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
-    case 13: {
-        auto k = k_ldl<13, 1>;
-        const size_t lds = ((104 * 105) / 2 + 8 + 104 + 8) * 8;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(64), lds, s, out, in, reps, m);
-        break;
-    }
-    case 8: {
-        auto k = k_ldl<8, 1>;
-        const size_t lds = ((64 * 65) / 2 + 8 + 64 + 8) * 8;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(64), lds, s, out, in, reps, m);
-        break;
-    }
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;

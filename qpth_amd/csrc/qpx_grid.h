@@ -297,6 +297,35 @@ QPX_DEV void block_matTvec(const Block& blk, T* out, const T* Mat, const T* vec,
     }
 }
 
+// out[r] (op)= sum_c Mat[r][c] * vec[c]  -- row dots: a wave takes RB rows at a time, its lanes stride over the
+// columns (coalesced), RB independent loads in flight per lane, then RB wave reductions.
+template <class T, int MODE /*0: =, 1: +=, 2: -=*/>
+QPX_DEV void block_matvec(const Block& blk, T* out, const T* Mat, const T* vec, int rows, int cols)
+{
+    constexpr int RB = 4;
+    const int lane = blk.lane(), w = blk.uniform(blk.wave()), nw = blk.nwaves();
+    for (int r0 = w * RB; r0 < rows; r0 += nw * RB) {
+        T acc[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) acc[u] = T(0);
+        for (int c = lane; c < cols; c += kWave) {
+            const T x = vec[c];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = (r0 + u < rows) ? r0 + u : rows - 1;      // clamped: loads stay unconditional
+                acc[u] = fma_(Mat[(size_t)r * cols + c], x, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) acc[u] = wave_sum(blk, acc[u]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+                if (r0 + u < rows) out[r0 + u] = MODE == 0 ? acc[u] : (MODE == 1 ? out[r0 + u] + acc[u] : out[r0 + u] - acc[u]);
+        }
+    }
+}
+
 // One pivot of the symmetric sweep operator on the register-resident matrix (pivot k = 16*KB + ka):
 //   E_ij -= v_i v_j / d for i, j != k,   E_ik = E_ki = v_i / d,   E_kk = -1/d,   v = column k.
 // Pivots k < npos must be positive (SPD Q), the others negative (-A Q^-1 A^T).
@@ -383,7 +412,7 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
     constexpr int GS = 16, NT = 256, MA = GS * NBL;
     const GridPos<GS> g(blk);
     const int n = a.n, m = a.m, q = a.q, nq = n + q, na = n + q + m;
-    const FacLayout lay = fac_layout(n, m, q);
+    const FacLayout lay = fac_layout(n, m, q, a.images);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const T* Qg = a.Q + (size_t)qp * a.sQ;
     const T* Gg = a.G + (size_t)qp * a.sG;
@@ -468,8 +497,7 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
                 }
             } else {
                 const int zi = i - nq;
-                if (j < n) {                                                     // M (m x n) and M^T
-                    F[lay.M + (size_t)zi * n + j] = val;
+                if (j < n) {                                                     // M^T (n x m): the coalesced direction
                     F[lay.MT + (size_t)j * m + zi] = val;
                 } else if (j < nq) {
                     F[lay.W + (size_t)zi * q + (j - n)] = val;                   // W (m x q)
@@ -497,7 +525,7 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
     QPX_PROF(3)
     {
         const Block& b = blk;
-        QPX_PROF_DUMP(F + lay.T, T)
+        QPX_PROF_DUMP(F + lay.prof, T)
     }
     if (blk.tid == 0) a.status[qp] = 0;
 }
@@ -513,7 +541,7 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     constexpr int M8 = Mat::MP, NT = Mat::NT;
     const typename Mat::Pos g(b);
     const int n = a.n, m = a.m, q = a.q;
-    const FacLayout lay = fac_layout(n, m, q);
+    const FacLayout lay = fac_layout(n, m, q, a.images);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const T* Rg = Mat::image(F, lay);
     // compile-time vector stride (64 NS >= max(n, MP, q)): every LDS vector is then a constant offset
@@ -841,7 +869,7 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     // zhat = x0 - M^T z' = -K p + N b - M^T z'
     block_matTvec<T, 0>(b, vX, F + lay.Kneg, vP, n, n);
     Mat::sync(b);
-    block_matTvec<T, 2>(b, vX, F + lay.M, vA, m, n);
+    block_matvec<T, 2>(b, vX, F + lay.MT, vA, n, m);
     if (q > 0) {
         Mat::sync(b);
         block_matTvec<T, 2>(b, vX, F + lay.NTn, vTm, q, n);
@@ -879,7 +907,7 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
     constexpr int M8 = Mat::MP, NT = Mat::NT;
     const typename Mat::Pos g(b);
     const int n = a.n, m = a.m, q = a.q;
-    const FacLayout lay = fac_layout(n, m, q);
+    const FacLayout lay = fac_layout(n, m, q, a.images);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const size_t v = align4(max2(max2((size_t)n, (size_t)M8), (size_t)q));
     T* rd = lds;
@@ -944,7 +972,7 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
     // dx = Kneg rx - M^T dz + NTn^T ry     (Kneg = -K, NTn = -N^T)
     block_matTvec<T, 0>(b, vDX, F + lay.Kneg, vRX, n, n);
     Mat::sync(b);
-    block_matTvec<T, 2>(b, vDX, F + lay.M, vDZ, m, n);
+    block_matvec<T, 2>(b, vDX, F + lay.MT, vDZ, n, m);
     if (q > 0) {
         Mat::sync(b);
         block_matTvec<T, 1>(b, vDX, F + lay.NTn, vRY, q, n);
@@ -967,31 +995,40 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
         for (int i = b.tid; i < q; i += NT) a.dy[(size_t)qp * q + i] = vDY[i];
         return;
     }
-    // ---- gradients (qp.py:157-173)
+    // ---- gradients (qp.py:157-173); a NULL output = that gradient is not wanted (ctx.needs_input_grad)
     for (int i = b.tid; i < n; i += NT) {
         vZH[i] = a.zhat[(size_t)qp * n + i];
-        a.dp[(size_t)qp * n + i] = vDX[i];
+        if (a.dp) a.dp[(size_t)qp * n + i] = vDX[i];
     }
     for (int i = b.tid; i < m; i += NT) {
         vLM[i] = a.lam[(size_t)qp * m + i];
-        a.dh[(size_t)qp * m + i] = -vDZ[i];
+        if (a.dh) a.dh[(size_t)qp * m + i] = -vDZ[i];
     }
     for (int i = b.tid; i < q; i += NT) {
         vNU[i] = a.nu[(size_t)qp * q + i];
-        a.db[(size_t)qp * q + i] = -vDY[i];
+        if (a.db) a.db[(size_t)qp * q + i] = -vDY[i];
     }
+    // the solution of the backward KKT system itself, for callers that reduce shared-parameter gradients
+    // over the batch as one contraction (qpx_batch_outer) instead of B outer products
+    if (a.dx) for (int i = b.tid; i < n; i += NT) a.dx[(size_t)qp * n + i] = vDX[i];
+    if (a.dz) for (int i = b.tid; i < m; i += NT) a.dz[(size_t)qp * m + i] = vDZ[i];
+    if (a.dy) for (int i = b.tid; i < q; i += NT) a.dy[(size_t)qp * q + i] = vDY[i];
     Mat::sync(b);
-    T* dQ = a.dQ + (size_t)qp * n * n;
-    for (int idx = b.tid; idx < n * n; idx += NT) {
-        const int r = idx / n, c = idx - r * n;
-        dQ[idx] = T(0.5) * (vDX[r] * vZH[c] + vZH[r] * vDX[c]);
+    if (a.dQ) {
+        T* dQ = a.dQ + (size_t)qp * n * n;
+        for (int idx = b.tid; idx < n * n; idx += NT) {
+            const int r = idx / n, c = idx - r * n;
+            dQ[idx] = T(0.5) * (vDX[r] * vZH[c] + vZH[r] * vDX[c]);
+        }
     }
-    T* dG = a.dG + (size_t)qp * m * n;
-    for (int idx = b.tid; idx < m * n; idx += NT) {
-        const int r = idx / n, c = idx - r * n;
-        dG[idx] = vDZ[r] * vZH[c] + vLM[r] * vDX[c];
+    if (a.dG) {
+        T* dG = a.dG + (size_t)qp * m * n;
+        for (int idx = b.tid; idx < m * n; idx += NT) {
+            const int r = idx / n, c = idx - r * n;
+            dG[idx] = vDZ[r] * vZH[c] + vLM[r] * vDX[c];
+        }
     }
-    if (q > 0) {
+    if (q > 0 && a.dA) {
         T* dA = a.dA + (size_t)qp * q * n;
         for (int idx = b.tid; idx < q * n; idx += NT) {
             const int r = idx / n, c = idx - r * n;

@@ -5,8 +5,9 @@
 // do not fit.  Kernels are stream-ordered, allocate nothing and never synchronise the host.
 //
 // Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm (workgroup per QP),
-// 3 = kkt/backward, 4 = ipm (wave per QP), 5 = sweep pre-factorisation (16x16 thread grid),
-// 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only).
+// 3 = kkt/backward, 5 = sweep pre-factorisation (16x16 thread grid),
+// 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only),
+// 10 = batch-mean outer products of shared-parameter gradients.
 #include <hip/hip_runtime.h>
 
 #include "../../include/qpx.h"
@@ -87,26 +88,6 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream)
 #define QPX_INST(NS, L)                                                                              \
     template int launch_kkt<QPX_TU_REAL, NS, L, false>(const KktArgs<QPX_TU_REAL>&, size_t, void*); \
     template int launch_kkt<QPX_TU_REAL, NS, L, true>(const KktArgs<QPX_TU_REAL>&, size_t, void*);
-#elif QPX_TU_KERNEL == 4
-template <class T, int NB, int NS>
-__global__ __launch_bounds__(kWave) void k_ipm_wave(IpmArgs<T> a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    ipm_wave_body<T, NB, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
-}
-template <class T, int NB, int NS>
-int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
-{
-    auto kern = k_ipm_wave<T, NB, NS>;
-    static bool big_lds_enabled = false;
-    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kWave), lds_bytes, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
-}
-#define QPX_INSTW(NB, NS) \
-    template int launch_ipm_wave<QPX_TU_REAL, NB, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
-QPX_INSTW(2, 1) QPX_INSTW(2, 2) QPX_INSTW(4, 1) QPX_INSTW(4, 2) QPX_INSTW(8, 1) QPX_INSTW(8, 2) QPX_INSTW(13, 2)
 #elif QPX_TU_KERNEL == 5
 template <class T, int NBL> __global__ __launch_bounds__(256) void k_sweep(PrefactorArgs<T> a)
 {
@@ -180,6 +161,8 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
 }
 #define QPX_INSTG(NBL, NS) template int launch_ipm_grid8<QPX_TU_REAL, NBL, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) QPX_INSTG(8, 2) QPX_INSTG(13, 2)
+#elif QPX_TU_KERNEL == 10
+// defined below, outside the launcher chain
 #elif QPX_TU_KERNEL == 9
 // NW waves per QP, always at least two waves per SIMD (<= 256 registers per lane): at that occupancy the
 // compiler keeps MFMA accumulators in VGPRs.  (At one wave per SIMD it moves every tile through AGPRs --
@@ -263,6 +246,23 @@ QPX_INSTT(1, 1, 1) QPX_INSTT(1, 1, 2) QPX_INSTT(1, 1, 4) QPX_INSTT(2, 1, 1) QPX_
 QPX_INSTT(4, 1, 1) QPX_INSTT(4, 1, 2) QPX_INSTT(4, 1, 4) QPX_INSTT(4, 2, 1) QPX_INSTT(4, 2, 2) QPX_INSTT(4, 2, 4)
 QPX_INSTT(7, 2, 2) QPX_INSTT(7, 2, 4) QPX_INSTT(7, 4, 2) QPX_INSTT(7, 4, 4)
 #endif
+#endif
+
+#if QPX_TU_KERNEL == 10
+template <class T> __global__ __launch_bounds__(64) void k_batch_outer(OuterArgs<T> a)
+{
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    batch_outer_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y);
+}
+template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int chunks, void* stream)
+{
+    if (a.use_atomics &&
+        hipMemsetAsync(a.out, 0, (size_t)a.r * a.c * sizeof(T), (hipStream_t)stream) != hipSuccess)
+        return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_batch_outer<T>, dim3(tiles, chunks), dim3(64), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+template int launch_batch_outer<QPX_TU_REAL>(const OuterArgs<QPX_TU_REAL>&, int, int, void*);
 #endif
 
 #if QPX_TU_KERNEL >= 1 && QPX_TU_KERNEL <= 3

@@ -287,7 +287,7 @@ template <class T> struct PrefactorArgs {
     T* fac;
     size_t fac_stride;
     int* status;
-    int images;                           // sweep path: which register images of R to write (1 Rg, 2 Rw, 4 Rm)
+    int images;                           // blob family / register images of R (qpx_layout.h: fac_layout)
 };
 
 template <class T> struct IpmArgs {
@@ -302,6 +302,7 @@ template <class T> struct IpmArgs {
     int *iters, *status;
     T* best_resid;
     T* trace;                             // optional [maxIter][B][3]: pri_resid, dual_resid, mu
+    int images;                           // blob family the factors were written in (fac_layout)
 };
 
 template <class T> struct KktArgs {
@@ -313,8 +314,9 @@ template <class T> struct KktArgs {
     T *dx, *ds, *dz, *dy;
     // backward (qp.py:127-182): d is built from lam/slack, rx = dl_dz
     const T *zhat, *lam, *slack, *nu, *dl_dz;
-    T *dQ, *dp, *dG, *dh, *dA, *db;
+    T *dQ, *dp, *dG, *dh, *dA, *db;       // backward: any of them may be NULL (gradient not wanted)
     int* status;
+    int images;                           // blob family the factors were written in (fac_layout)
 };
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB of LDS per workgroup
@@ -347,7 +349,7 @@ template <class T, int NS, bool kLds>
 QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T* lds)
 {
     const int n = a.n, m = a.m, q = a.q;
-    const FacLayout lay = fac_layout(n, m, q);
+    const FacLayout lay = fac_layout(n, m, q, 0);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const T* Qg = a.Q + (size_t)qp * a.sQ;
     const T* Gg = a.G + (size_t)qp * a.sG;
@@ -375,9 +377,6 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
     }
 
     QPX_PROF_INIT
-    // register-layout copy of R for the wave-per-QP kernel: zero it first (padding, upper parts)
-    if (lay.nbw > 0)
-        for (size_t e = b.tid; e < (size_t)(lay.nbw * (lay.nbw + 1) / 2) * 64; e += b.nt) F[lay.Rw + e] = T(0);
     // A. symmetrised lower triangle of Q -> packed
     for (int idx = b.tid; idx < n * n; idx += b.nt) {
         const int i = idx / n, j = idx - i * n;
@@ -497,12 +496,6 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
                     const int i = 4 * ti + r, j = 4 * tj + c;
                     if (i < m && j <= i) {
                         Rg[tri(i) + j] = acc[r][c];
-                        if (lay.nbw > 0) {
-                            const int li = i >> 3, ai = i & 7, lj = j >> 3, bj = j & 7;
-                            T* blk = F + lay.Rw + (size_t)(li * (li + 1) / 2 + lj) * 64;
-                            blk[ai + 8 * bj] = acc[r][c];
-                            if (li == lj && i != j) blk[bj + 8 * ai] = acc[r][c];   // diagonal blocks are held in full
-                        }
                     }
                 }
         }
@@ -542,7 +535,7 @@ QPX_DEV void prefactor_body(const Block& b, const PrefactorArgs<T>& a, int qp, T
     if (b.tid == 0) a.status[qp] = 0;
     b.sync();
     QPX_PROF(5)
-    QPX_PROF_DUMP(F + lay.T, T)
+    QPX_PROF_DUMP(F + lay.prof, T)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -601,7 +594,7 @@ template <class T, int NS, bool kLds>
 QPX_DEV void ipm_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
 {
     const int n = a.n, m = a.m, q = a.q;
-    const FacLayout lay = fac_layout(n, m, q);
+    const FacLayout lay = fac_layout(n, m, q, 0);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const T* Rg = F + lay.R;
     const size_t v = align4(max2(max2((size_t)n, (size_t)m), (size_t)q));
@@ -962,7 +955,7 @@ template <class T, int NS, bool kLds, bool kBackward>
 QPX_DEV void kkt_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
 {
     const int n = a.n, m = a.m, q = a.q;
-    const FacLayout lay = fac_layout(n, m, q);
+    const FacLayout lay = fac_layout(n, m, q, 0);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const size_t v = align4(max2(max2((size_t)n, (size_t)m), (size_t)q));
     T* dinv = lds;
@@ -1074,7 +1067,8 @@ QPX_DEV void kkt_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
                 vdz[i] = x[k];
                 const T dsv = (-rs[k] - x[k]) / d[k];
                 if (kBackward) {
-                    a.dh[(size_t)qp * m + i] = -x[k];                       // qp.py:161
+                    if (a.dh) a.dh[(size_t)qp * m + i] = -x[k];             // qp.py:161
+                    if (a.dz) a.dz[(size_t)qp * m + i] = x[k];
                 } else {
                     a.dz[(size_t)qp * m + i] = x[k];
                     a.ds[(size_t)qp * m + i] = dsv;
@@ -1102,8 +1096,10 @@ QPX_DEV void kkt_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
             for (int sa = 0; sa < NS; ++sa) {
                 const int r = sa * kWave + lane;
                 if (r < q) {
-                    if (kBackward) a.db[(size_t)qp * q + r] = -y[sa];       // qp.py:166
-                    else a.dy[(size_t)qp * q + r] = y[sa];
+                    if (kBackward) {
+                        if (a.db) a.db[(size_t)qp * q + r] = -y[sa];        // qp.py:166
+                        if (a.dy) a.dy[(size_t)qp * q + r] = y[sa];
+                    } else a.dy[(size_t)qp * q + r] = y[sa];
                     vrho[r] = vyt[r] - vrho[r];                             // Yt - rho
                 }
             }
@@ -1133,8 +1129,10 @@ QPX_DEV void kkt_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
             const int i = k * kWave + lane;
             if (i < n) {
                 vw[i] = -x[k];
-                if (kBackward) a.dp[(size_t)qp * n + i] = -x[k];            // qp.py:157
-                else a.dx[(size_t)qp * n + i] = -x[k];
+                if (kBackward) {
+                    if (a.dp) a.dp[(size_t)qp * n + i] = -x[k];             // qp.py:157
+                    if (a.dx) a.dx[(size_t)qp * n + i] = -x[k];
+                } else a.dx[(size_t)qp * n + i] = -x[k];
             }
         }
     }
@@ -1146,17 +1144,17 @@ QPX_DEV void kkt_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
         for (int j = b.tid; j < m; j += b.nt) vh[j] = a.lam[(size_t)qp * m + j];
         for (int r = b.tid; r < q; r += b.nt) vyt[r] = a.nu[(size_t)qp * q + r];
         b.sync();
-        T* dQ = a.dQ + (size_t)qp * n * n;
-        for (int idx = b.tid; idx < n * n; idx += b.nt) {
+        T* dQ = a.dQ ? a.dQ + (size_t)qp * n * n : nullptr;        // NULL = gradient not wanted
+        for (int idx = b.tid; dQ && idx < n * n; idx += b.nt) {
             const int r = idx / n, cidx = idx - r * n;
             dQ[idx] = T(0.5) * (vw[r] * vt[cidx] + vt[r] * vw[cidx]);
         }
-        T* dG = a.dG + (size_t)qp * m * n;
-        for (int idx = b.tid; idx < m * n; idx += b.nt) {
+        T* dG = a.dG ? a.dG + (size_t)qp * m * n : nullptr;
+        for (int idx = b.tid; dG && idx < m * n; idx += b.nt) {
             const int r = idx / n, cidx = idx - r * n;
             dG[idx] = vdz[r] * vt[cidx] + vh[r] * vw[cidx];
         }
-        if (q > 0) {
+        if (q > 0 && a.dA) {
             T* dA = a.dA + (size_t)qp * q * n;
             for (int idx = b.tid; idx < q * n; idx += b.nt) {
                 const int r = idx / n, cidx = idx - r * n;

@@ -6,9 +6,9 @@
 #include <type_traits>
 
 #include "qpx_kernels.h"
-#include "qpx_wave.h"
 #include "qpx_grid.h"
 #include "qpx_tile.h"
+#include "qpx_reduce.h"
 
 namespace qpx {
 
@@ -25,9 +25,6 @@ template <class T, int NS, bool kLds>
 int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
 template <class T, int NS, bool kLds, bool kBw>
 int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream);
-// wave-per-QP PDIPM loop (qpx_wave.h): workgroup = one wave64
-template <class T, int NB, int NS>
-int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
 
 // thread-grid kernels (qpx_grid.h), 16x16 threads per QP, format-3 blob
 template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream);
@@ -37,5 +34,8 @@ template <int NBL, int NW> int launch_prefactor_tile(const PrefactorArgs<double>
 template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream);
 template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void* stream);   // 8x8 grid = one wave
 template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void* stream);
+
+// batch-mean outer products of shared-parameter gradients (qpx_reduce.h): grid (tiles, batch chunks), one wave each
+template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int chunks, void* stream);
 
 }  // namespace qpx

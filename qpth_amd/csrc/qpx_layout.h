@@ -1,25 +1,39 @@
 // qpx_layout.h -- HBM layout of the per-QP "factor blob" and shared constants.
 //
 // The blob is what the reference keeps in (Q_LU, S_LU, R) between pre_factor_kkt, the IPM loop
-// and backward (qpth/solvers/pdipm/batch.py:375-429, qpth/qp.py:93,150-155), re-expressed for
-// an un-pivoted Cholesky design (SPD Q and S; the reference's own GPU branch is un-pivoted,
-// batch.py:8-20).  One blob per QP, `fac_stride` elements apart, all sub-arrays 16-byte aligned:
+// and backward (qpth/solvers/pdipm/batch.py:375-429, qpth/qp.py:93,150-155).  One blob per QP,
+// `fac_stride` elements apart, all sub-arrays 16-byte aligned.  There are two families, chosen by
+// the dispatcher from (dtype, n, m, q) alone (qpx_api.inc: blob_images):
+//
+// (a) thread-grid / matrix-core kernels, n+q+m <= 208 (`images` != 0): what the symmetric sweep of
+//     the augmented matrix leaves behind (qpx_grid.h: sweep_body) -- no triangular factors at all:
+//
+//   Kneg   n x n      -K,  K = Q^-1 - Q^-1 A^T S11^-1 A Q^-1  (both triangles)
+//   MT     n x m      (G K)^T: M p is a column-parallel sum over its rows, M^T z a row dot
+//   NTn    q x n      -N^T,  N = Q^-1 A^T S11^-1
+//   W      m x q      G N
+//   S11i   q x q      (A Q^-1 A^T)^-1
+//   scal   4          [0] = || G^T 1 ||_2 ; [4..11] phase timers of the profiling build
+//   R = G K G^T (the reference's R, batch.py:396-399,424) in the REGISTER IMAGE(S) its consumers load,
+//   `images` bit 1: Rg  16x16 thread grid, entry [(li(li+1)/2 + lj)*256 + a + 16b] = R[16li+a][16lj+b]
+//            bit 2: Rw  8x8 thread grid (one wave), entry [(li(li+1)/2 + lj)*64 + a + 8b]
+//            bit 4: Rm  16x16 tiles in the C/D layout of v_mfma_f64_16x16x4 (tile_image_index)
+//   (f64 with m <= 112: Rm only; otherwise Rg + Rw).
+//
+// (b) workgroup kernels (qpx_kernels.h), any size up to 512 (`images` == 0): un-pivoted Cholesky
+//     factors (the reference's own GPU branch is un-pivoted, batch.py:8-20):
 //
 //   L      n(n+1)/2   Cholesky factor of Q, packed lower, row-major        (replaces Q_LU)
 //   dinvL  n          1 / L_kk
 //   Zp     n x m      P L^-1 G^T, P = projector onto null(A L^-T) (= L^-1 G^T when neq = 0)
-//   R      m(m+1)/2   Zp^T Zp = G Q^-1 G^T - G Q^-1 A^T (A Q^-1 A^T)^-1 A Q^-1 G^T, packed lower
-//                     (the reference's R, batch.py:396-399,424)
+//   R      m(m+1)/2   Zp^T Zp, packed lower
 //   Yh     n x q      L^-1 A^T L11^-T (orthonormal columns)
 //   V      q x m      Yh^T L^-1 G^T
 //   L11    q(q+1)/2   Cholesky factor of A Q^-1 A^T, packed lower          (replaces S_LU[:q,:q])
 //   dinv11 q
 //   r1     m          R 1
-//   scal   4          [0] = || G^T 1 ||_2
+//   scal   4 (+8)
 //   T      m(m+1)/2   scratch: Cholesky factor of R + diag(1/d) when it does not fit in LDS
-//   Rw     64*nb(nb+1)/2  R again, in the REGISTER LAYOUT of the wave-per-QP kernel (qpx_wave.h):
-//                     entry [(li(li+1)/2 + lj)*64 + a + 8b] = R[8li+a][8lj+b], li >= lj, zero padded to
-//                     8*nb x 8*nb; nb = wave_nb(m); absent (nb = 0) when m is too large for that kernel
 #pragma once
 #include <cstddef>
 
@@ -35,9 +49,8 @@ QPX_LAYOUT_HD size_t tri(size_t i) { return i * (i + 1) / 2; }
 QPX_LAYOUT_HD int tri(int i) { return i * (i + 1) / 2; }   // 32-bit form for kernel index math
 QPX_LAYOUT_HD size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
 
-// Number of 8-row blocks the wave-per-QP kernel is instantiated with for nineq = m (0: not
-// available, the workgroup kernel runs instead).  One list for both dtypes so that the blob
-// layout does not depend on dtype.
+// Number of 8-row blocks the 8x8 thread-grid (one wave per QP) loop kernel is instantiated with for
+// nineq = m (0: not available).
 QPX_LAYOUT_HD int wave_nb(int m)
 {
     const int need = (m + 7) / 8;
@@ -91,54 +104,59 @@ QPX_LAYOUT_HD int sweep_nb(int ord)
 }
 
 struct FacLayout {
-    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, scal, T, Rw;
-    // "format 3" (grid kernels: sweep pre-factorisation, no triangular factors), present when
-    // grid_nb(n+q+m) > 0:  Kneg = -K (n x n, full), M = G K (m x n), MT = M^T (n x m),
-    // NTn = -N^T = -(A K')... (q x n), W = G N (m x q), S11i = (A Q^-1 A^T)^-1 (q x q),
-    // Rg = R in the 16x16 grid register layout (gtri(nbg) * 256)
-    size_t Kneg, M, MT, NTn, W, S11i, Rg;
-    // Rm = R in the tile-register layout of qpx_tile.h (tile_image_elems(nbt) elements, entry
-    // tile_image_index(i, j)), present when format 3 is and tile_nb(m) > 0
-    size_t Rm;
+    // family (b)
+    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, T;
+    // family (a)
+    size_t Kneg, MT, NTn, W, S11i, Rg, Rw, Rm;
+    size_t scal, prof;
     size_t total;
-    int nbw;      // wave kernel blocks of 8 for m (0 = n/a)
+    int images;   // 0: family (b); else bit mask of the R images present (1 Rg, 2 Rw, 4 Rm)
+    int nbw;      // 8x8-grid blocks of 8 for m (0 = n/a)
     int nbg;      // grid blocks of 16 for m
-    int nba;      // grid blocks of 16 for the augmented order n+q+m (0 = format 3 unavailable)
+    int nba;      // grid blocks of 16 for the augmented order n+q+m (0 = family (a) unavailable)
     int nbt;      // tile rows of 16 for m in the matrix-core kernels (0 = n/a)
 };
 
-QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q)
+// can the thread-grid / tile kernels run this size at all?
+QPX_LAYOUT_HD bool grid_family_fits(int n, int m, int q) { return grid_nb(n + q + m) > 0; }
+
+QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q, int images)
 {
     FacLayout f;
     size_t o = 0;
-    f.L = o;      o += align4(tri(n));
-    f.dinvL = o;  o += align4(n);
-    f.Zp = o;     o += align4((size_t)n * m);
-    f.R = o;      o += align4(tri(m));
-    f.Yh = o;     o += align4((size_t)n * q);
-    f.V = o;      o += align4((size_t)q * m);
-    f.L11 = o;    o += align4(tri(q));
-    f.dinv11 = o; o += align4(q);
-    f.r1 = o;     o += align4(m);
-    f.scal = o;   o += 4;
-    f.T = o;      o += align4(tri(m));
-    f.nbw = wave_nb(m);
-    f.Rw = o;     o += (size_t)(f.nbw * (f.nbw + 1) / 2) * 64;
-    f.nba = grid_nb(n + q + m);
-    f.nbg = f.nba > 0 ? grid_nb(m) : 0;
-    f.Kneg = f.M = f.MT = f.NTn = f.W = f.S11i = f.Rg = o;
-    if (f.nba > 0) {
+    f.images = images;
+    f.L = f.dinvL = f.Zp = f.R = f.Yh = f.V = f.L11 = f.dinv11 = f.r1 = f.T = 0;
+    f.Kneg = f.MT = f.NTn = f.W = f.S11i = f.Rg = f.Rw = f.Rm = 0;
+    f.nbw = f.nbg = f.nba = f.nbt = 0;
+    if (images == 0) {
+        f.L = o;      o += align4(tri((size_t)n));
+        f.dinvL = o;  o += align4(n);
+        f.Zp = o;     o += align4((size_t)n * m);
+        f.R = o;      o += align4(tri((size_t)m));
+        f.Yh = o;     o += align4((size_t)n * q);
+        f.V = o;      o += align4((size_t)q * m);
+        f.L11 = o;    o += align4(tri((size_t)q));
+        f.dinv11 = o; o += align4(q);
+        f.r1 = o;     o += align4(m);
+        f.scal = o;   o += 4;
+        f.prof = o;   o += 8;
+        f.T = o;      o += align4(tri((size_t)m));
+    } else {
+        f.nba = grid_nb(n + q + m);
+        f.nbg = grid_nb(m);
+        f.nbw = wave_nb(m);
+        f.nbt = tile_nb(m);
         f.Kneg = o; o += align4((size_t)n * n);
-        f.M = o;    o += align4((size_t)m * n);
         f.MT = o;   o += align4((size_t)n * m);
         f.NTn = o;  o += align4((size_t)q * n);
         f.W = o;    o += align4((size_t)m * q);
         f.S11i = o; o += align4((size_t)q * q);
-        f.Rg = o;   o += (size_t)(f.nbg * (f.nbg + 1) / 2) * 256;
+        f.scal = o; o += 4;
+        f.prof = o; o += 8;
+        f.Rg = o;   if (images & 1) o += (size_t)(f.nbg * (f.nbg + 1) / 2) * 256;
+        f.Rw = o;   if ((images & 2) && f.nbw > 0) o += (size_t)(f.nbw * (f.nbw + 1) / 2) * 64;
+        f.Rm = o;   if ((images & 4) && f.nbt > 0) o += tile_image_elems(f.nbt);
     }
-    f.nbt = f.nba > 0 ? tile_nb(m) : 0;
-    f.Rm = o;
-    if (f.nbt > 0) o += tile_image_elems(f.nbt);
     f.total = o;
     return f;
 }

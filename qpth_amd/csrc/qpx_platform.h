@@ -95,7 +95,22 @@ struct Block {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         c[0] = acc[0]; c[1] = acc[1]; c[2] = acc[2]; c[3] = acc[3];
     }
+    // the f32 form (v_mfma_f32_16x16x4_f32): same operands, but the accumulator layout differs -- lane
+    // l holds c[r] = C[4 (l >> 4) + r][l & 15]
+    QPX_DEV void mfma16x16x4(float a, float b, float (&c)[4]) const
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 acc = {c[0], c[1], c[2], c[3]};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        c[0] = acc[0]; c[1] = acc[1]; c[2] = acc[2]; c[3] = acc[3];
+    }
+    // row of the 16x16 accumulator tile that register r of lane group g holds
+    static QPX_HD int mfma_row(double, int g, int r) { return g + 4 * r; }
+    static QPX_HD int mfma_row(float, int g, int r) { return 4 * g + r; }
 };
+
+QPX_DEV void atomic_add_(float* p, float v) { atomicAdd(p, v); }
+QPX_DEV void atomic_add_(double* p, double v) { atomicAdd(p, v); }
 
 // Rows of 64 consecutive elements of a wave-uniform global array, read as one coalesced
 // 64-lane load each: row(r) = base[r*64 + lane].  Implemented with buffer loads (SGPR resource

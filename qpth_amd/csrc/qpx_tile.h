@@ -493,7 +493,7 @@ QPX_DEV void prefactor_tile_body(const Block& b, const PrefactorArgs<double>& a,
     constexpr int MP = Mat::MP, NT = Mat::NT, NPOS = Mat::NPOS;
     const typename Mat::Pos p(b);
     const int n = a.n, m = a.m, q = a.q, nq = n + q, P4 = aug_pivots(n, q), na = P4 + m;
-    const FacLayout lay = fac_layout(n, m, q);
+    const FacLayout lay = fac_layout(n, m, q, a.images);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const T* Qg = a.Q + (size_t)qp * a.sQ;
     const T* Gg = a.G + (size_t)qp * a.sG;
@@ -560,7 +560,6 @@ QPX_DEV void prefactor_tile_body(const Block& b, const PrefactorArgs<double>& a,
                 const int zi = i - P4;
                 const T val = -E.e[Mat::slot(pp, J)][r];
                 if (j < n) {
-                    F[lay.M + (size_t)zi * n + j] = val;
                     F[lay.MT + (size_t)j * m + zi] = val;
                 } else if (j < nq) {
                     F[lay.W + (size_t)zi * q + (j - n)] = val;

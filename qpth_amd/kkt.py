@@ -60,9 +60,6 @@ def _pinned_ints(device, count, nring=16):
 
 
 class KKTFactors:
-    def __init__(self):
-        self.d = None
-
     @classmethod
     def build(cls, Q, G, A, nBatch=None):
         """pre_factor_kkt(Q, G, A)   (batch.py:375-429); enqueues one kernel, no host sync."""
@@ -77,8 +74,8 @@ class KKTFactors:
                 tuple(Q.shape), tuple(G.shape), tuple(A.shape) if A is not None else ()))
         self.lib = _lib.backend_for(Q)
         self.dtype, self.device = Q.dtype, Q.device
-        self.elems = self.lib.factor_elems(self.n, self.m, self.q)
         code = _lib.QPX_F64 if Q.dtype == torch.float64 else _lib.QPX_F32
+        self.elems = self.lib.factor_elems(code, self.n, self.m, self.q)
         fits = bool(self.lib.dll.qpx_fits_lds(code, self.n, self.m, self.q))
         self.shared = B > 1 and fits and _is_shared(Q, B) and _is_shared(G, B) and _is_shared(A, B)
         nblob = 1 if self.shared else B
@@ -165,17 +162,42 @@ a non-zero diagonal.
                                   self._vec(rz, m), self._vec(ry, q), dx, ds, dz, dy, self.status)
         return dx, ds, dz, dy
 
-    # -- QPFunctionFn.backward (qp.py:127-182), per-QP gradients ---------------------------------
-    def backward(self, zhat, lam, slacks, nu, dl_dz):
+    # -- QPFunctionFn.backward (qp.py:127-182) ------------------------------------------------
+    def backward(self, zhat, lam, slacks, nu, dl_dz, want=(True,) * 6, shared=(False,) * 6):
+        """Gradients (dQ, dp, dG, dh, dA, db) for the parameters `want` asks for (ctx.needs_input_grad;
+        the others come back as None and cost nothing).  A parameter flagged in `shared` is one the whole
+        batch shares: its gradient is returned already reduced to the reference's `.mean(0)` (qp.py:159-177)
+        -- for the matrices by one contraction over the batch (qpx_batch_outer) instead of B outer products."""
         B, n, m, q = self.B, self.n, self.m, self.q
         dt, dev = self.dtype, self.device
-        dQ = torch.empty(B, n, n, dtype=dt, device=dev)
-        dp = torch.empty(B, n, dtype=dt, device=dev)
-        dG = torch.empty(B, m, n, dtype=dt, device=dev)
-        dh = torch.empty(B, m, dtype=dt, device=dev)
-        dA = torch.empty(B, q, n, dtype=dt, device=dev) if q else None
-        db = torch.empty(B, q, dtype=dt, device=dev) if q else None
-        self.lib.backward(B, n, m, q, self.blob, self.sfac, self._vec(zhat, n), self._vec(lam, m),
-                          self._vec(slacks, m), self._vec(nu, q), self._vec(dl_dz, n),
-                          dQ, dp, dG, dh, dA, db, self.status)
+        wQ, wp, wG, wh, wA, wb = [bool(w) for w in want]
+        sQ, sp, sG, sh, sA, sb = [bool(s) for s in shared]
+        if q == 0:
+            wA = wb = False
+
+        def buf(flag, *shape):
+            return torch.empty(*shape, dtype=dt, device=dev) if flag else None
+
+        dQ = buf(wQ and not sQ, B, n, n)
+        dG = buf(wG and not sG, B, m, n)
+        dA = buf(wA and not sA, B, q, n)
+        need_dx = wp or (wQ and sQ) or (wG and sG) or (wA and sA)
+        dx = buf(need_dx, B, n)                                   # dp = dx  (qp.py:157)
+        dz = buf(wh or (wG and sG), B, m)                         # dh = -dz (qp.py:161)
+        dy = buf(q > 0 and (wb or (wA and sA)), B, q)             # db = -dy (qp.py:166)
+        zh, lm, nv = self._vec(zhat, n), self._vec(lam, m), self._vec(nu, q)
+        self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m), nv,
+                          self._vec(dl_dz, n), dQ, None, dG, None, dA, None, self.status, dx, dz, dy)
+        if wQ and sQ:
+            dQ = torch.empty(n, n, dtype=dt, device=dev)
+            self.lib.batch_outer(dx, zh, zh, dx, 0.5, dQ)
+        if wG and sG:
+            dG = torch.empty(m, n, dtype=dt, device=dev)
+            self.lib.batch_outer(dz, zh, lm, dx, 1.0, dG)
+        if wA and sA:
+            dA = torch.empty(q, n, dtype=dt, device=dev)
+            self.lib.batch_outer(dy, zh, nv, dx, 1.0, dA)
+        dp = (dx.mean(0) if sp else dx) if wp else None
+        dh = ((-dz).mean(0) if sh else -dz) if wh else None
+        db = ((-dy).mean(0) if sb else -dy) if wb else None
         return dQ, dp, dG, dh, dA, db

@@ -68,8 +68,8 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                 zhats, ctx.nus, ctx.lams, ctx.slacks = res.zhat, res.nu, res.lam, res.slacks
             elif solver == QPSolvers.CVXPY:
                 # forward by an external CPU solver, backward by the HIP kernels (qp.py:97-120,142-143)
-                from .solvers import cvxpy as cvx_solver
-                zhats, ctx.nus, ctx.lams, ctx.slacks = cvx_solver.forward_batch(Q, p, G, h, A, b, neq)
+                from .solvers import external
+                zhats, ctx.nus, ctx.lams, ctx.slacks = external.forward_batch(Q, p, G, h, A, b, neq)
                 ctx.fac = None
             else:
                 assert False
@@ -94,26 +94,15 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                 fac = KKTFactors.build(Q, G, A, nBatch)
                 fac.raise_on_failure(check_Q_spd)
 
-            # d = clamp(lams)/clamp(slacks), factor_kkt, solve_kkt(dl_dzhat, 0, 0, 0) and the
-            # outer products (qp.py:148-173) happen inside one kernel
-            dQs, dps, dGs, dhs, dAs, dbs = fac.backward(zhats, ctx.lams, ctx.slacks, ctx.nus, dl_dzhat)
-
-            if G_e:
-                dGs = dGs.mean(0)
-            if h_e:
-                dhs = dhs.mean(0)
-            if neq > 0:
-                if A_e:
-                    dAs = dAs.mean(0)
-                if b_e:
-                    dbs = dbs.mean(0)
-            else:
-                dAs, dbs = None, None
-            if Q_e:
-                dQs = dQs.mean(0)
-            if p_e:
-                dps = dps.mean(0)
-
-            grads = (dQs, dps, dGs, dhs, dAs, dbs)
+            # d = clamp(lams)/clamp(slacks), factor_kkt, solve_kkt(dl_dzhat, 0, 0, 0) and the outer
+            # products (qp.py:148-173) happen inside one kernel.  Only the gradients autograd asks for are
+            # formed (ctx.needs_input_grad), and the `.mean(0)` of a parameter the batch shares
+            # (qp.py:159-177) is taken inside KKTFactors.backward -- for Q, G, A as one contraction over
+            # the batch instead of nBatch outer products.
+            want = tuple(ctx.needs_input_grad[:6])
+            grads = fac.backward(zhats, ctx.lams, ctx.slacks, ctx.nus, dl_dzhat, want=want,
+                                 shared=(Q_e, p_e, G_e, h_e, A_e, b_e))
+            if neq == 0:
+                grads = grads[:4] + (None, None)
             return grads
     return QPFunctionFn.apply

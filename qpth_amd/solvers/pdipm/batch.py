@@ -11,7 +11,7 @@ Differences that are visible to a caller, all documented in DESIGN.md:
   * Q_LU / S_LU / R are opaque handles onto one device-resident factor blob (Cholesky based;
     the reference's GPU branch of lu_hack is un-pivoted as well, batch.py:8-20) -- they can be
     passed around exactly like the reference's tuples but not indexed;
-  * factor_kkt only records `d`: the m x m factor lives in LDS and is rebuilt by the kernel
+  * factor_kkt only checks `d`: the m x m factor lives in registers / LDS and is built by the kernel
     that consumes it (solve_kkt / backward), which is cheaper than a round trip through HBM;
   * the IPM loop runs per QP (one workgroup each); the reference's batch-global stopping
     test and get_step quirk are replaced by their batch-of-one meaning (`stall_policy`).
@@ -68,8 +68,13 @@ def pre_factor_kkt(Q, G, A):
 
 
 def factor_kkt(S_LU, R, d):
-    """Factor the U22 block that we can only do after we know D."""
-    S_LU.fac.d = d
+    """Factor the U22 block that we can only do after we know D.
+
+    Here the m x m factor of R + diag(1/d) never leaves the registers / LDS of the kernel that consumes it
+    (solve_kkt below takes `d` again, exactly as the reference's signature does), so this call only checks
+    its arguments."""
+    if d.size(-1) != S_LU.fac.m:
+        raise RuntimeError("factor_kkt: d has %d entries, nineq is %d" % (d.size(-1), S_LU.fac.m))
 
 
 def solve_kkt(Q_LU, d, G, A, S_LU, rx, rs, rz, ry):

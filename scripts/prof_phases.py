@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import problems  # noqa: E402
 from qpth_amd import _lib  # noqa: E402
 from qpth_amd.kkt import KKTFactors  # noqa: E402
@@ -29,8 +29,9 @@ def main():
     for rep in range(3):
         res = fac.ipm(tp, th, tb, want_trace=True)
         torch.cuda.synchronize()
-    from qpth_amd.csrc_layout import fac_layout_T_offset
-    pre = fac.blob.reshape(B, -1)[:, fac_layout_T_offset(n, m, q):][:, :8].double().cpu().numpy()
+    from csrc_layout import prof_offset
+    images = 0 if (int(os.environ.get("QPX_VARIANT", "0")) & 255) == 1 or n + m + q > 208 else 1
+    pre = fac.blob.reshape(B, -1)[:, prof_offset(n, m, q, images):][:, :8].double().cpu().numpy()
     pn = ["load Q + chol(Q)", "load G^T, |G^T 1|", "TRSM Z=L^-1 G^T", "equality block", "SYRK R=Z^T Z", "r1 + spill to blob", "-", "-"]
     if lib.dll.qpx_set_ipm_variant(int(os.environ.get("QPX_VARIANT", "0"))) is None:
         pass

@@ -43,23 +43,3 @@ for blocks in (1, 512, 2048):
         extra = "   | full division %.1f" % b2.mean() if w == 6 else ""
         print("  %-40s mean %8.1f  min %8.1f max %8.1f%s" % (names[w], a.mean(), a.min(), a.max(), extra))
 
-# real routines on a real matrix: R of the C2 workload in register layout
-from qpth_amd.kkt import KKTFactors  # noqa: E402
-from qpth_amd.csrc_layout import fac_layout_T_offset  # noqa: E402
-for (B, n, m, which, nb) in ((512, 100, 100, 13, 13), (2048, 64, 64, 8, 8), (64, 100, 100, 13, 13)):
-    arrs = problems.prof_qp(B, n, m, 0, 0)
-    tQ, tp, tG, th, tA, tb = [torch.tensor(x, device=dev) for x in arrs]
-    fac = KKTFactors.build(tQ, tG, tA, B)
-    torch.cuda.synchronize()
-    tri = m * (m + 1) // 2
-    off = fac_layout_T_offset(n, m, 0) + ((tri + 3) & ~3)
-    rw = fac.blob.reshape(B, -1)[:, off:off + (nb * (nb + 1) // 2) * 64].contiguous()
-    # make T = R + I so that the factorisation is well posed: add 1 to the diagonal entries (a == b lanes of diagonal blocks)
-    rwv = rw.view(B, nb * (nb + 1) // 2, 64)
-    for l in range(nb):
-        e = l * (l + 1) // 2 + l
-        for a in range(8):
-            rwv[:, e, a + 8 * a] += 1.0
-    tl, tf, ts = run(which, B, 5, m, rw)
-    print("wave_ldl NB=%d m=%d, %d waves: ldl %.0f cycles (%.0f/col)  fwd subst %.0f (%.1f/step)  bwd subst %.0f (%.1f/step)" % (
-        nb, m, B, tl.mean(), tl.mean() / (8 * nb), tf.mean(), tf.mean() / m, ts.mean(), ts.mean() / m))

@@ -13,9 +13,9 @@
 #include "../../include/qpx.h"
 #include "qpx_platform.h"  // the emulation header: defines QPX_PLATFORM_H, so the HIP one is skipped
 #include "qpx_kernels.h"
-#include "qpx_wave.h"
 #include "qpx_grid.h"
 #include "qpx_tile.h"
+#include "qpx_reduce.h"
 
 // Extra bytes behind the emulated LDS block.  The sanitizer build uses 0 so that an index one element past
 // the size the launcher computed is already a reported overflow.
@@ -121,17 +121,6 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void*)
     return QPX_OK;
 }
 
-template <class T, int NB, int NS>
-int launch_ipm_wave(const IpmArgs<T>& a, size_t lds_bytes, void*)
-{
-    for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
-        T* base = reinterpret_cast<T*>(lds.data());
-        run_block(kWave, [&](const Block& b) { ipm_wave_body<T, NB, NS>(b, a, qp, base); });
-    }
-    return QPX_OK;
-}
-
 template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
@@ -193,6 +182,15 @@ template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, s
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(256, [&](const Block& b) { kkt_grid_body<T, 16, NBL, kBw>(b, a, qp, base); });
     }
+    return QPX_OK;
+}
+
+template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int chunks, void*)
+{
+    if (a.use_atomics)
+        for (size_t e = 0; e < (size_t)a.r * a.c; ++e) a.out[e] = T(0);
+    for (int ch = 0; ch < chunks; ++ch)
+        for (int t = 0; t < tiles; ++t) run_block(64, [&](const Block& b) { batch_outer_body<T>(b, a, t, ch); });
     return QPX_OK;
 }
 

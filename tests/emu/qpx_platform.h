@@ -86,7 +86,35 @@ struct Block {
         }
         pthread_barrier_wait(&sh->wave_bar[wave()]);
     }
+    // f32 form: accumulator register r of lane group g is row 4 g + r
+    void mfma16x16x4(float a, float b, float (&c)[4]) const
+    {
+        unsigned long long ba = 0, bb = 0;
+        std::memcpy(&ba, &a, 4);
+        std::memcpy(&bb, &b, 4);
+        sh->xchg[tid] = ba;
+        sh->xchg2[tid] = bb;
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        const int base = tid & ~(kWave - 1), g = lane() >> 4, cc = lane() & 15;
+        for (int r = 0; r < 4; ++r) {
+            float acc = c[r];
+            for (int k = 0; k < 4; ++k) {
+                float av, bv;
+                std::memcpy(&av, &sh->xchg[base + (k << 4) + (4 * g + r)], 4);
+                std::memcpy(&bv, &sh->xchg2[base + (k << 4) + cc], 4);
+                acc = std::fma(av, bv, acc);
+            }
+            c[r] = acc;
+        }
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+    }
+    static int mfma_row(double, int g, int r) { return g + 4 * r; }
+    static int mfma_row(float, int g, int r) { return 4 * g + r; }
 };
+
+// workgroups run one after the other in the emulation: a plain add is the atomic
+inline void atomic_add_(float* p, float v) { *p += v; }
+inline void atomic_add_(double* p, double v) { *p += v; }
 
 template <class T> struct GlobalRows {
     const T* base;

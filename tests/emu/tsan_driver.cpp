@@ -46,7 +46,7 @@ int main(int argc, char** argv)
             bb[(size_t)s * q + i] = acc;
         }
     }
-    const size_t fe = qpx_factor_elems(n, m, q);
+    const size_t fe = qpx_factor_elems(QPX_F64, n, m, q);
     std::vector<double> fac((size_t)B * fe), zhat((size_t)B * n), nu((size_t)B * q + 1), lam((size_t)B * m), sl((size_t)B * m), br(B);
     std::vector<int32_t> status(B), iters(B);
     int rc = qpx_pre_factor(QPX_F64, B, n, m, q, Q.data(), (int64_t)n * n, G.data(), (int64_t)m * n, q ? A.data() : nullptr,
@@ -57,10 +57,20 @@ int main(int argc, char** argv)
                  nullptr, nullptr);
     if (rc) { fprintf(stderr, "ipm rc %d\n", rc); return 2; }
     std::vector<double> g((size_t)B * n, 1.0), dQ((size_t)B * n * n), dp((size_t)B * n), dG((size_t)B * m * n), dh((size_t)B * m);
-    std::vector<double> dA((size_t)B * q * n + 1), db((size_t)B * q + 1);
+    std::vector<double> dA((size_t)B * q * n + 1), db((size_t)B * q + 1), dx((size_t)B * n), dz((size_t)B * m), dy((size_t)B * q + 1);
     rc = qpx_backward(QPX_F64, B, n, m, q, fac.data(), (int64_t)fe, zhat.data(), lam.data(), sl.data(), q ? nu.data() : nullptr, g.data(),
-                      dQ.data(), dp.data(), dG.data(), dh.data(), q ? dA.data() : nullptr, q ? db.data() : nullptr, status.data(), nullptr);
+                      dQ.data(), dp.data(), dG.data(), dh.data(), q ? dA.data() : nullptr, q ? db.data() : nullptr,
+                      dx.data(), dz.data(), q ? dy.data() : nullptr, status.data(), nullptr);
     if (rc) { fprintf(stderr, "backward rc %d\n", rc); return 2; }
+    // the shared-parameter reduction (batch-mean of dQ as one contraction over the batch)
+    std::vector<double> dQm((size_t)n * n);
+    rc = qpx_batch_outer(QPX_F64, B, n, n, dx.data(), zhat.data(), zhat.data(), dx.data(), 0.5, dQm.data(), nullptr);
+    if (rc) { fprintf(stderr, "batch_outer rc %d\n", rc); return 2; }
+    for (int i = 0; i < n * n; ++i) {
+        double acc = 0;
+        for (int s = 0; s < B; ++s) acc += dQ[(size_t)s * n * n + i];
+        if (std::fabs(acc / B - dQm[i]) > 1e-9 * (1.0 + std::fabs(dQm[i]))) { fprintf(stderr, "batch_outer mismatch at %d\n", i); return 3; }
+    }
     double worst = 0;
     for (int s = 0; s < B; ++s) {
         for (int i = 0; i < m; ++i) {                               // primal feasibility G z <= h

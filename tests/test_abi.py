@@ -39,9 +39,12 @@ def test_hip_library_exports_every_declared_symbol(built):
 def test_hip_library_loads_and_answers_metadata(built):
     from qpth_amd import _lib
     lib = _lib.QpxLib(built)
-    assert lib.dll.qpx_abi_version() == 1
+    assert lib.dll.qpx_abi_version() == 2
     assert lib.dll.qpx_max_dim() == 512
-    assert lib.factor_elems(100, 100, 0) > 100 * 100
+    # factor blob per QP: -K, (G K)^T and ONE register image of R -- 217 KB at C2 in f64 (<= 250 KB),
+    # 5.5 GB for all 65 536 QPs of C5 (<= 6 GB)
+    assert 100 * 100 * 2 < lib.factor_elems(_lib.QPX_F64, 100, 100, 0) * 8 <= 250 * 1024
+    assert lib.factor_elems(_lib.QPX_F64, 64, 64, 0) * 8 * 65536 <= 6 * 2 ** 30
     assert lib.dll.qpx_fits_lds(_lib.QPX_F64, 100, 100, 0) == 1      # C2 runs LDS-resident in f64
     assert lib.dll.qpx_fits_lds(_lib.QPX_F64, 500, 500, 0) == 0      # C4 does not
     assert b"not supported" in lib.dll.qpx_strerror(-2)
