@@ -1,23 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- the headline metric of BASELINE.json on MI355X.
+"""bench.py -- the headline metric of BASELINE.json on MI355X, and the reference's two timing tables.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                    (the driver's contract)
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path over one batch of synthetic QPs that is already resident
-in HBM:  z = QPFunction(verbose=-1)(Q, p, G, h, A, b); z.backward(ones)   (forward + backward,
-the measurement defined in SURVEY.md section 8d / prof-linear.py:110-118, device-synchronised).
-Workload = BASELINE.json configs[1] extended with the backward pass as its `metric` asks:
-batch=512, nz=100, nineq=100, neq=0 per GPU, float64 (the dtype the 1e-4 parity gate holds in).
-With N GPUs every rank solves its own 512-QP shard (the batch dimension shards with no
-data-path collective) => weak scaling; value = N*512*K / max-over-ranks time.
+One "step" = one pass of the hot path over one batch of synthetic QPs that is already resident in HBM:
+    z = QPFunction(verbose=-1)(Q, p, G, h, A, b); z.backward(ones)        (forward + backward)
+the measurement of SURVEY.md section 8d / prof-linear.py:110-118, device-synchronised, `p` requiring grad as in
+prof-linear.py:99.  Default workload = BASELINE.json configs[1] extended with the backward pass as its `metric`
+asks: batch=512, nz=100, nineq=100, neq=0, float64 (the dtype the 1e-4 parity gate holds in).
+
+Multi-GPU (one process per GPU, RCCL):
+  --config c2 (default)  every rank solves its own 512-QP shard and the ranks all_gather zhat (the only exchange
+                         the path has, north_star / SURVEY 8e) inside the timed region  => "scaling": "weak"
+  --config c5            BASELINE.json configs[4]: a FIXED global batch of 65 536 QPs (nz=nineq=64) split by
+                         qpth_amd.dist.shard_bounds, zhat gathered                       => "scaling": "strong"
 
 The JSON line also carries
-  roofline ...... the dominant kernel (k_ipm, the PDIPM loop): algorithmic bytes per launch /
-                  average launch duration measured live with HIP events on the launch stream
-  cpu_baseline .. the oracle (C restatement of the reference's CPU path) timed on this host
+  roofline ...... the dominant kernel (the PDIPM loop): algorithmic flops and bytes per launch / the launch's
+                  duration measured live with HIP events on the launch stream; `traffic` = HBM bytes per launch
+                  from the PMC passes of scripts/gpu_check.sh, reported only if they were taken on THIS build
+  cpu_baseline .. the oracle (C restatement of the reference's CPU path, OpenMP over QPs) timed on this host
+  fwd_only ...... QPs/s of the forward alone (BASELINE.json configs[1] as written)
+  kernel_ms ..... per-launch HIP-event times, incl. the loop with early stopping off (all maxIter iterations =
+                  the work the reference does) and the backward with every gradient requested
+
+Tables of the reference's timing scripts (one JSON line per row, after the headline line is suppressed):
+  --table prof-linear   prof-linear.py:38-61: batch 128, nz = nineq in {10, 50, 100, 500}, forward and backward
+                        timed separately, f32 and f64
+  --table prof-gurobi   prof-gurobi.py:37-48,115-118: nz=100 (dense Q), nineq=100, batch in {1, 64, 128},
+                        pre_factor_kkt + forward only
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,7 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import problems  # noqa: E402
 from qpth_amd.qp import QPFunction  # noqa: E402
 from qpth_amd.kkt import KKTFactors, set_stall_policy  # noqa: E402
-from qpth_amd import _lib  # noqa: E402
+from qpth_amd import _lib, dist as qdist  # noqa: E402
 
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 # Dense f64 / f32 peaks.  f32: 157.3 TF (MI355X_MICROARCH.md, matrix = vector).  f64: the guide has no
@@ -41,6 +56,10 @@ HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 # micro-benchmarks agree: v_fma_f64 issues every 4.07 ticks per wave (77 TF over 1024 SIMDs at the
 # measured 2.39 GHz tick), v_mfma_f64_16x16x4 every 83 ticks (60 TF) -- scripts/ubench_mfma.py.
 MFMA_PEAK = {"f64": 78.6e12, "f32": 157.3e12}
+# The reference's own PyTorch-CPU PDIPM on this workload, measured in the survey session (SURVEY.md section 6 /
+# 8 threads of a Xeon, MKL LAPACK): it cannot be re-timed on the GPU box (no
+# /root/reference there), so it is quoted next to the port that can.
+REFERENCE_CPU_QPS = {"f64": 222.0, "f32": 629.0}
 
 
 def algorithmic_flops_per_qp(n, m, q, iters):
@@ -64,20 +83,113 @@ def algorithmic_bytes_per_qp(n, m, q, w):
     return fwd_r, fwd_w, bwd_r, bwd_w
 
 
+def kernel_source_digest():
+    """sha256 over the kernel sources: identifies the BUILD a PMC measurement belongs to (a git commit would
+    change with every documentation edit)."""
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "qpth_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".inc")) or name == "Makefile":
+            hsh.update(name.encode())
+            hsh.update(open(os.path.join(d, name), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def time_launches(fn, nrep):
+    """average duration of `fn`'s launches by HIP events on the launch stream (torch's current stream)"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(nrep):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / nrep * 1e-3
+
+
+def make_batch(B, n, m, q, seed, np_dt, dev):
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed=seed, dtype=np_dt)
+    return (Q, p, G, h, A, b), [torch.tensor(x, device=dev) for x in (Q, p, G, h, A, b)]
+
+
+# ---------------------------------------------------------------------------------------------- tables
+def table_prof_linear(dev, args):
+    """prof-linear.py:38-61,95-123: nBatch = 128, nz = nineq in {10, 50, 100, 500}, neq = 0; forward and
+    backward timed separately (device-synchronised), p requires grad; both dtypes."""
+    rows = []
+    for dtype, np_dt in (("f32", np.float32), ("f64", np.float64)):
+        for nz in (10, 50, 100, 500):
+            B = 128
+            _, (tQ, tp, tG, th, tA, tb) = make_batch(B, nz, nz, 0, 0, np_dt, dev)
+            tp.requires_grad_(True)
+            ones = torch.ones(B, nz, dtype=tQ.dtype, device=dev)
+            qpf = QPFunction(verbose=-1)
+            ntr = 3 if nz >= 500 else 10
+            fw, bw = [], []
+            for i in range(ntr + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                z = qpf(tQ, tp, tG, th, tA, tb)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                z.backward(ones)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                tp.grad = None
+                if i:
+                    fw.append(t1 - t0)
+                    bw.append(t2 - t1)
+            rows.append({"table": "prof-linear", "dtype": dtype, "nBatch": B, "nz": nz, "nineq": nz, "neq": 0,
+                         "forward_ms": float(np.median(fw)) * 1e3, "backward_ms": float(np.median(bw)) * 1e3,
+                         "qps_fwd_bwd": B / (float(np.median(fw)) + float(np.median(bw))), "trials": ntr})
+            print(json.dumps(rows[-1]), flush=True)
+    return rows
+
+
+def table_prof_gurobi(dev, args):
+    """prof-gurobi.py:37-48,109-118: nz = 100, nineq = 100, neq = 0, nBatch in {1, 64, 128}; the timed region is
+    pre_factor_kkt + forward only (no backward), f64 as in the script (`.double()`)."""
+    from qpth_amd.solvers.pdipm import batch as pdipm_b
+    rows = []
+    for B in (1, 64, 128):
+        _, (tQ, tp, tG, th, tA, tb) = make_batch(B, 100, 100, 0, 0, np.float64, dev)
+        ts = []
+        for i in range(11):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(tQ, tG, tA)
+            pdipm_b.forward(tQ, tp, tG, th, tA, tb, Q_LU, S_LU, R, verbose=-1)
+            torch.cuda.synchronize()
+            if i:
+                ts.append(time.perf_counter() - t0)
+        rows.append({"table": "prof-gurobi", "dtype": "f64", "nBatch": B, "nz": 100, "nineq": 100, "neq": 0,
+                     "pre_factor_plus_forward_ms": float(np.median(ts)) * 1e3, "qps_forward": B / float(np.median(ts))})
+        print(json.dumps(rows[-1]), flush=True)
+    return rows
+
+
+# ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--nz", type=int, default=100)
-    ap.add_argument("--nineq", type=int, default=100)
-    ap.add_argument("--neq", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "custom"],
+                    help="c2: B=512 nz=100 nineq=100 per GPU (default, weak scaling); c3: B=512 nz=100 nineq=50 "
+                         "neq=10 per GPU; c4: B=128 nz=nineq=500 per GPU; c5: fixed GLOBAL batch 65536, nz=nineq=64 "
+                         "(strong scaling); custom: --batch/--nz/--nineq/--neq per GPU")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--nz", type=int, default=None)
+    ap.add_argument("--nineq", type=int, default=None)
+    ap.add_argument("--neq", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fixed-iters", action="store_true",
-                    help="also time the loop kernel with early stopping off (all maxIter iterations); off by "
-                         "default so that every launch of the loop kernel in a profiled run does the same work")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave zhat on its rank (no all_gather)")
+    ap.add_argument("--shared", action="store_true",
+                    help="Q, G, A shared by the batch (SURVEY 8f-1): one pre-factorisation for the whole batch, "
+                         "shared-parameter gradients reduced by qpx_batch_outer (+ all_reduce at N > 1)")
+    ap.add_argument("--table", default=None, choices=["prof-linear", "prof-gurobi"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,23 +205,56 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if os.environ.get("QPX_VARIANT"):            # A/B knob for kernel development (include/qpx.h)
+        _lib.hip().dll.qpx_set_ipm_variant(int(os.environ["QPX_VARIANT"]))
 
-    B, n, m, q = args.batch, args.nz, args.nineq, args.neq
+    if args.table:
+        assert world == 1, "--table runs on one GPU"
+        (table_prof_linear if args.table == "prof-linear" else table_prof_gurobi)(dev, args)
+        return
+
+    presets = {"c2": (512, 100, 100, 0), "c3": (512, 100, 50, 10), "c4": (128, 500, 500, 0), "c5": (65536, 64, 64, 0)}
+    if args.config == "custom" or any(v is not None for v in (args.batch, args.nz, args.nineq, args.neq)):
+        base = presets.get(args.config, presets["c2"])
+        Bcfg, n, m, q = [v if v is not None else d for v, d in zip((args.batch, args.nz, args.nineq, args.neq), base)]
+    else:
+        Bcfg, n, m, q = presets[args.config]
+    strong = args.config == "c5"
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     w = 8 if args.dtype == "f64" else 4
-    # every rank owns its own shard: different seed per rank, same generator (prof-linear.py:64-75)
-    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed=rank, dtype=np_dt)
-    tQ, tp, tG, th, tA, tb = [torch.tensor(x, device=dev) for x in (Q, p, G, h, A, b)]
+    if strong:
+        # fixed global batch: this rank's contiguous slice, generated per shard from a per-rank seed
+        lo, hi = qdist.shard_bounds(Bcfg, rank, world)
+        B, global_B = hi - lo, Bcfg
+    else:
+        B, global_B = Bcfg, Bcfg * world
+    host, (tQ, tp, tG, th, tA, tb) = make_batch(B, n, m, q, rank, np_dt, dev)
+    if args.shared:
+        tQ, tG = tQ[0].contiguous(), tG[0].contiguous()
+        tz0 = torch.randn(B, n, dtype=tQ.dtype, device=dev)
+        th = tz0 @ tG.t() + torch.rand(B, m, dtype=tQ.dtype, device=dev)
+        if q:
+            tA = tA[0].contiguous()
+            tb = tz0 @ tA.t()
+        tQ.requires_grad_(True)
+        tG.requires_grad_(True)
     tp.requires_grad_(True)                      # prof-linear.py:99
     ones = torch.ones(B, n, dtype=tQ.dtype, device=dev)
     qpf = QPFunction(verbose=-1)
-    if os.environ.get("QPX_VARIANT"):            # A/B knob for kernel development (include/qpx.h)
-        _lib.hip().dll.qpx_set_ipm_variant(int(os.environ["QPX_VARIANT"]))
+    gather = distributed and not args.no_gather
 
     def step():
         z = qpf(tQ, tp, tG, th, tA, tb)
         z.backward(ones)
+        if gather:
+            qdist.gather_batch(z.detach(), global_B)                       # zhat for the caller's autograd graph
+        if args.shared and distributed:
+            qdist.reduce_shared_grad(tQ.grad, B, global_B)
+            qdist.reduce_shared_grad(tG.grad, B, global_B)
         tp.grad = None
+        if args.shared:
+            tQ.grad = None
+            tG.grad = None
         return z
 
     def barrier():
@@ -122,7 +267,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        z = step()
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
@@ -130,65 +275,78 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
+    value = global_B * args.steps / dt
+
+    # median over chunks of 10 steps: the box-to-box and run-to-run spread the single total hides (every rank
+    # runs them: a step contains collectives at N > 1)
+    chunk_ms = []
+    for _ in range(min(10, max(3, args.steps // 10))):
+        barrier()
+        c0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        barrier()
+        chunk_ms.append((time.perf_counter() - c0) / 10 * 1e3)
 
     if rank == 0:
         # ---- per-kernel timing with HIP events on the launch stream (torch's current stream) ----
-        fac = KKTFactors.build(tQ, tG, tA, B)
+        dQ, dG, dA = tQ.detach(), tG.detach(), tA.detach() if q else tA
+        fac = KKTFactors.build(dQ, dG, dA, B)
         res = fac.ipm(tp.detach(), th, tb)
         torch.cuda.synchronize()
-        iters_mean = float(res.iters.float().mean().item())
-        nrep = max(5, min(args.steps, 30))
-
-        def time_launches(fn):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(nrep):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / nrep * 1e-3
-
-        t_pre = time_launches(lambda: KKTFactors.build(tQ, tG, tA, B))
-        t_ipm = time_launches(lambda: fac.ipm(tp.detach(), th, tb))
-        t_bwd = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones))
-        t_ipm_fixed = None
-        if args.fixed_iters:
-            set_stall_policy(_lib.STALL_OFF)
-            t_ipm_fixed = time_launches(lambda: fac.ipm(tp.detach(), th, tb))
-            set_stall_policy(None)
+        iters = res.iters.cpu().numpy()
+        iters_mean = float(iters.mean())
+        nrep = 50 if n + m <= 256 else 5
+        t_pre = time_launches(lambda: KKTFactors.build(dQ, dG, dA, B), nrep)
+        t_ipm = time_launches(lambda: fac.ipm(tp.detach(), th, tb), nrep)
+        want_p = (False, True, False, False, False, False)
+        t_bwd = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones, want=want_p), nrep)
+        t_bwd_all = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones), nrep)
+        set_stall_policy(_lib.STALL_OFF)
+        t_ipm_fixed = time_launches(lambda: fac.ipm(tp.detach(), th, tb), max(3, nrep // 3))
+        set_stall_policy(None)
+        # forward only = BASELINE.json configs[1] as written (QPFunction forward, no backward)
+        with torch.no_grad():
+            t_fwd = time_launches(lambda: qpf(dQ, tp.detach(), dG, th, dA, tb), nrep)
 
         fwd_r, fwd_w, bwd_r, bwd_w = algorithmic_bytes_per_qp(n, m, q, w)
         ipm_bytes = (fwd_r + fwd_w) * B          # the forward's compulsory traffic, DESIGN.md section 6
-        # The loop kernel is compute-side bound (55 flop per compulsory byte at C2, machine balance ~10):
+        # The loop kernel is compute-side bound (48 flop per compulsory byte at C2, machine balance ~10):
         # its roofline is the dense matrix/vector peak of the dtype it computes in.
         ipm_flops = algorithmic_flops_per_qp(n, m, q, iters_mean) * B
         achieved = ipm_flops / t_ipm
         peak = MFMA_PEAK[args.dtype]
-        traffic = None
+        traffic, traffic_note = None, "no PMC record for this configuration"
         tf = os.path.join(ROOT, "profiles", "ipm_traffic.json")
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf))
-                if rec.get("config") == [B, n, m, q, args.dtype]:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                if rec.get("config") != [B, n, m, q, args.dtype]:
+                    traffic_note = "PMC record is for config %s" % rec.get("config")
+                elif rec.get("kernel_source_digest") != kernel_source_digest():
+                    traffic_note = "PMC record is of another build (%s); re-run scripts/gpu_check.sh" % rec.get("kernel_source_digest")
+                else:
+                    traffic, traffic_note = rec.get("hbm_bytes_per_launch"), rec.get("source")
+            except Exception as e:                      # a broken record is reported, never silently reused
+                traffic_note = "unreadable PMC record: %s" % e
         roofline = {"kernel": "PDIPM loop kernel (k_ipm_tile / k_ipm_grid, one launch per forward)", "bound": "mfma",
                     "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": traffic, "algorithmic_flops_per_launch": ipm_flops,
+                    "traffic": traffic, "traffic_source": traffic_note,
+                    "algorithmic_flops_per_launch": ipm_flops,
                     "algorithmic_bytes_per_launch": ipm_bytes, "hbm_frac": ipm_bytes / t_ipm / HBM_PEAK,
-                    "launch_ms": t_ipm * 1e3}
+                    "launch_ms": t_ipm * 1e3, "kernel_source_digest": kernel_source_digest()}
 
         cpu_baseline = None
-        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not args.shared:      # reported at N = 1 only
             from oracle import qp_oracle as orc
             ncpu = os.cpu_count() or 1
-            np1 = np.ones((B, n), np_dt)
+            Bs = B if n + m <= 256 else min(B, 32)       # bounded sample: the full C2 batch; 32 QPs at C4 size
+            sQ, sp, sG, sh, sA, sb = [x[:Bs] if x.ndim > 1 or x.size else x for x in host]
+            np1 = np.ones((Bs, n), np_dt)
 
             def cpu_pass(nth):
                 c0 = time.perf_counter()
-                o = orc.OracleQP(Q, p, G, h, A, b, nthreads=nth)
+                o = orc.OracleQP(sQ, sp, sG, sh, sA, sb, nthreads=nth)
                 x, y, lam, s, info = o.forward()                      # reference (batch-global) semantics
                 o.backward(x, lam, s, y, np1)
                 return time.perf_counter() - c0, info
@@ -203,24 +361,36 @@ def main():
             for rep in range(2):
                 t, info = cpu_pass(cores)
                 best = min(best, t)
-            cpu_baseline = {"value": B / best, "unit": "QPs/s", "cores": cores, "kind": "port",
-                            "sample": "the full workload once (B=%d fwd+bwd, best of 3 at the best OpenMP team size "
-                                      "of a scan over 4..128 threads, %s, %d IPM iterations, %d host CPUs)"
-                                      % (B, args.dtype, int(info["trips"]), ncpu)}
+            cpu_baseline = {"value": Bs / best, "unit": "QPs/s", "cores": cores, "kind": "port",
+                            "sample": "B=%d QPs of the workload, fwd+bwd, best of 3 at the best OpenMP team size of a "
+                                      "scan over 4..128 threads, %s, all %d IPM iterations of the reference's batch-global "
+                                      "loop (the GPU loop stops each QP when it has converged: %.1f on average), %d host "
+                                      "CPUs.  The reference's own PyTorch-CPU PDIPM on this workload: %.0f QPs/s (%s, 8 "
+                                      "threads, survey session; it cannot run on the GPU box)"
+                                      % (Bs, args.dtype, int(info["trips"]), iters_mean, ncpu,
+                                         REFERENCE_CPU_QPS[args.dtype], args.dtype),
+                            "reference_pytorch_cpu_qps": REFERENCE_CPU_QPS[args.dtype]}
 
+        names = {"c2": "C2", "c3": "C3", "c4": "C4", "c5": "C5", "custom": "custom"}
         out = {
             "metric": "QPs/sec (fwd+bwd) at batch=512 nz=100 nineq=100; 1/2/4/8 MI355X",
             "value": value, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "C2 fwd+bwd: batch=%d nz=%d nineq=%d neq=%d per GPU, dense random QP "
-                                   "(prof-linear.py generator), QPFunction(verbose=-1) defaults" % (B, n, m, q),
-                       "global_batch": world * B, "parallelism": "batch-sharded x%d" % world,
-                       "ipm_iterations_mean": iters_mean},
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s fwd+bwd: batch=%d nz=%d nineq=%d neq=%d %s, dense random QP (prof-linear.py "
+                                   "generator)%s, QPFunction(verbose=-1) defaults, p requires grad%s"
+                                   % (names[args.config], Bcfg, n, m, q, "GLOBAL (sharded)" if strong else "per GPU",
+                                      ", Q G A shared by the batch" if args.shared else "",
+                                      ", zhat all_gathered over RCCL" if gather else ""),
+                       "global_batch": global_B, "parallelism": "batch-sharded x%d" % world,
+                       "ipm_iterations_mean": iters_mean, "ipm_iterations_max": int(iters.max()),
+                       "ipm_iterations_histogram": np.bincount(iters, minlength=21).tolist()},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "ms_per_step_median_of_10_step_chunks": float(np.median(chunk_ms)),
+            "fwd_only": {"qps": B / t_fwd, "ms": t_fwd * 1e3, "what": "QPFunction forward under no_grad (BASELINE.json configs[1])"},
             "kernel_ms": {"pre_factor": t_pre * 1e3, "ipm": t_ipm * 1e3, "backward": t_bwd * 1e3,
-                          "ipm_all_20_iterations": None if t_ipm_fixed is None else t_ipm_fixed * 1e3},
+                          "backward_all_gradients": t_bwd_all * 1e3, "ipm_all_20_iterations": t_ipm_fixed * 1e3},
             "job_hbm_roofline_frac": value / world * (fwd_r + fwd_w + bwd_r + bwd_w) / HBM_PEAK,
         }
         print(json.dumps(out))

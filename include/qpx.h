@@ -88,12 +88,16 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * (or in HBM when they do not fit); 1 = always the workgroup kernels.
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
- * at 1 / 2 / 4, adding 16384 selects the (slower, experimental) tile pre-factorisation instead of the
- * thread-grid sweep; by default the library picks by dtype, size and batch.
+ * at 1 / 2 / 4; by default the library picks by dtype, size and batch.
  * The knob must not change between qpx_pre_factor and the calls that consume its factors (it selects the
  * layout of `factors` too: ask qpx_factor_elems after setting it).
  * Returns the previous value. */
 int qpx_set_ipm_variant(int variant);
+int qpx_get_ipm_variant(void);      /* the calling thread's current value */
+
+/* May a batch whose Q, G, A are shared be served by ONE factor blob (qpx_pre_factor with B = 1, consumers
+ * with sfac = 0)?  Always for the thread-grid / tile kernels; for the workgroup kernels only if qpx_fits_lds. */
+int qpx_can_share_factors(int dtype, int n, int m, int q);
 
 /* pre_factor_kkt(Q, G, A) */
 int qpx_pre_factor(int dtype, int B, int n, int m, int q,

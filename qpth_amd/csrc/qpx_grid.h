@@ -637,6 +637,8 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     // ---- pass -1 is the start point: T = R + I, z_i = -T^-1 c, s_i = -z_i, shifts (batch.py:61-87),
     // and R 1 on the way; passes 0.. are the IPM iterations.  One loop so that the factorisation and
     // the solves are instantiated once (they are the bulk of the kernel's code).
+    // (Re-loading R right after the last solve of the previous pass, so that the loads fly during wave 0's vector
+    // work, was measured: no gain -- profiles/r02b_panel_ab.txt, "late".)
     int stop = 0;
     for (int it = -1; it < a.maxIter && !stop; ++it) {
         const bool first = it < 0;

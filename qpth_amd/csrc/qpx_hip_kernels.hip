@@ -212,34 +212,11 @@ template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& 
 #define QPX_INSTK(NBL, NW)                                                                     \
     template int launch_kkt_tile<NBL, NW, false>(const KktArgs<double>&, size_t, void*);       \
     template int launch_kkt_tile<NBL, NW, true>(const KktArgs<double>&, size_t, void*);
-#if !defined(QPX_TILE_ONLY) && !defined(QPX_TILE_PRE_ONLY)
+#if !defined(QPX_TILE_ONLY)
 QPX_INSTK(1, 1) QPX_INSTK(2, 1) QPX_INSTK(4, 1) QPX_INSTK(4, 2) QPX_INSTK(7, 2) QPX_INSTK(7, 4)
 #endif
-// pre-factorisation on tiles: the augmented matrix (order <= 208) needs up to 91 tiles = 13 per wave at 8 waves
-template <int NBL, int NW>
-__global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void k_prefactor_tile(PrefactorArgs<double> a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    prefactor_tile_body<NBL, NW>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
-}
-template <int NBL, int NW> int launch_prefactor_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream)
-{
-    auto kern = k_prefactor_tile<NBL, NW>;
-    static bool big_lds_enabled = false;
-    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NW), lds_bytes, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
-}
-#define QPX_INSTP(NBL, NW) template int launch_prefactor_tile<NBL, NW>(const PrefactorArgs<double>&, size_t, void*);
-#ifdef QPX_TILE_PRE_ONLY
-QPX_INSTP(13, 8)
-#elif !defined(QPX_TILE_ONLY)
-QPX_INSTP(1, 1) QPX_INSTP(2, 1) QPX_INSTP(4, 2) QPX_INSTP(7, 4) QPX_INSTP(10, 5) QPX_INSTP(13, 8)
-#endif
 #define QPX_INSTT(NBL, NW, NS) template int launch_ipm_tile<NBL, NW, NS>(const IpmArgs<double>&, size_t, void*);
-#if defined(QPX_TILE_PRE_ONLY)
-#elif defined(QPX_TILE_ONLY)
+#if defined(QPX_TILE_ONLY)
 QPX_INSTT(7, QPX_TILE_ONLY, 2)
 #else
 QPX_INSTT(1, 1, 1) QPX_INSTT(1, 1, 2) QPX_INSTT(1, 1, 4) QPX_INSTT(2, 1, 1) QPX_INSTT(2, 1, 2) QPX_INSTT(2, 1, 4)

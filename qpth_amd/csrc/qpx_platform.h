@@ -12,6 +12,10 @@
 
 #define QPX_DEV __device__ __forceinline__
 #define QPX_HD __host__ __device__ __forceinline__
+// keep the compiler's scheduler from moving instructions across this point (order of MFMA groups and LDS writes)
+#ifndef QPX_SCHED_FENCE
+#define QPX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace qpx {
 

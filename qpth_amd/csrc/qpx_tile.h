@@ -464,169 +464,6 @@ QPX_DEV void kkt_tile_body(const Block& b, const KktArgs<double>& a, int qp, dou
     kkt_mat_body<double, TileMat<NBL, NW>, kBackward>(b, a, qp, lds);
 }
 
-// ------------------------------------------------------------------------------------------
-// Pre-factorisation on matrix-core tiles (f64): the same blob as sweep_body (qpx_grid.h) writes,
-// from the first n+q columns of ldl_inv on the augmented matrix
-//
-//        [ Q   A^T  .   G^T ]      rows/cols  0..n-1: Q,  n..n+q-1: A,  then identity up to a multiple of
-//   S =  [ A   0    .   0   ]      four (so that the panels end exactly where the pivots do),  then G.
-//        [ .   .    I   .   ]
-//        [ G   0    .   0   ]
-//
-// After eliminating the pivot columns (positive pivots for Q, negative for -A Q^-1 A^T): the rows of G
-// hold -[G 0] Kaug^-1 = -[M W] in the pivot columns and -R = -G K G^T in the trailing block; the pivot
-// block holds W~ = L~^-1 and rd = 1/d, from which Kaug^-1 = W~^T D^-1 W~ = [[K, N], [N^T, -S11^-1]] is
-// formed tile by tile on the matrix cores (a register tile is directly the A operand of its own
-// transpose and the B operand of itself, one k-slice per register) and summed over the waves in LDS.
-QPX_LAYOUT_HD size_t lds_elems_prefactor_tile(int nbl, int nw)
-{
-    const size_t mp = 16 * (size_t)nbl;
-    return 8 * mp + 40 + 2 * mp + 8 + (size_t)nw * 256;
-}
-QPX_LAYOUT_HD int aug_pivots(int n, int q) { return (n + q + 3) & ~3; }     // pivot columns incl. identity filler
-
-template <int NBL, int NW>
-QPX_DEV void prefactor_tile_body(const Block& b, const PrefactorArgs<double>& a, int qp, double* lds)
-{
-    using T = double;
-    using Mat = TileMat<NBL, NW>;
-    constexpr int MP = Mat::MP, NT = Mat::NT, NPOS = Mat::NPOS;
-    const typename Mat::Pos p(b);
-    const int n = a.n, m = a.m, q = a.q, nq = n + q, P4 = aug_pivots(n, q), na = P4 + m;
-    const FacLayout lay = fac_layout(n, m, q, a.images);
-    T* F = a.fac + (size_t)qp * a.fac_stride;
-    const T* Qg = a.Q + (size_t)qp * a.sQ;
-    const T* Gg = a.G + (size_t)qp * a.sG;
-    const T* Ag = q > 0 ? a.A + (size_t)qp * a.sA : nullptr;
-    T* scr = lds;                       // X | pivot blocks (the head of TileMat's scratch)
-    T* rd = lds + 8 * MP + 40;          // 1/d_k
-    T* cs = rd + MP;                    // column sums of G
-    T* red = cs + MP + 8;               // NW x 256: per-wave partial tiles
-
-    // ---- || G^T 1 ||
-    for (int j = b.tid; j < n; j += NT) {
-        T acc = 0;
-        for (int i = 0; i < m; ++i) acc += Gg[(size_t)i * n + j];
-        cs[j] = acc;
-    }
-    Mat::sync(b);
-    if (b.wave() == 0) {
-        T acc = 0;
-        for (int j = b.lane(); j < n; j += kWave) acc = fma_(cs[j], cs[j], acc);
-        acc = wave_sum(b, acc);
-        if (b.lane() == 0) F[lay.scal] = sqrt_(acc);
-    }
-    // ---- load the lower block triangle of S (diagonal tiles in full)
-    typename Mat::Regs E;
-#pragma unroll
-    for (int pp = 0; pp < NPOS; ++pp) {
-        const int I = p.row(pp);
-#pragma unroll
-        for (int J = 0; J < Mat::psize(pp); ++J) {
-            if (J > I) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int i = 16 * I + p.g + 4 * r, j = 16 * J + p.c;
-                if (j > i) { const int t = i; i = j; j = t; }
-                T val = (i == j) ? T(1) : T(0);                        // identity filler and padding
-                if (i < n) val = T(0.5) * (Qg[(size_t)i * n + j] + Qg[(size_t)j * n + i]);
-                else if (i < nq) val = (j < n) ? Ag[(size_t)(i - n) * n + j] : T(0);
-                else if (i >= P4 && i < na) val = (j < n) ? Gg[(size_t)(i - P4) * n + j] : T(0);
-                E.e[Mat::slot(pp, J)][r] = val;
-            }
-        }
-    }
-    // ---- eliminate the pivot columns
-    const int fail = Mat::ldl_inv_signed(b, p, E, scr, rd, P4, n, nq);
-    if (fail) {
-        for (size_t e = b.tid; e < lay.total; e += NT) F[e] = T(0);
-        if (b.tid == 0) a.status[qp] = (fail == 1) ? QPX_ST_Q_NOT_SPD : QPX_ST_A_RANK;
-        return;
-    }
-    // ---- the rows of G: M, M^T, W and the tile image of R
-    for (size_t e = b.tid; e < tile_image_elems(lay.nbt); e += NT) F[lay.Rm + e] = T(0);
-    Mat::sync(b);
-#pragma unroll
-    for (int pp = 0; pp < NPOS; ++pp) {
-        const int I = p.row(pp);
-        if (16 * I + 15 < P4) continue;
-#pragma unroll
-        for (int J = 0; J < Mat::psize(pp); ++J) {
-            if (J > I) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * I + p.g + 4 * r, j = 16 * J + p.c;
-                if (i < P4 || i >= na || j > i) continue;
-                const int zi = i - P4;
-                const T val = -E.e[Mat::slot(pp, J)][r];
-                if (j < n) {
-                    F[lay.MT + (size_t)j * m + zi] = val;
-                } else if (j < nq) {
-                    F[lay.W + (size_t)zi * q + (j - n)] = val;
-                } else if (j >= P4) {
-                    const int zj = j - P4;
-                    F[lay.Rm + tile_image_index(zi, zj)] = val;
-                    if ((zi >> 4) == (zj >> 4) && zi != zj) F[lay.Rm + tile_image_index(zj, zi)] = val;
-                }
-            }
-        }
-    }
-    // ---- Kaug^-1 = W~^T D^-1 W~, tile (I, J): sum over the tile rows L >= I of (L, I)^T D_L^-1 (L, J)
-    T dv[NPOS][4];
-#pragma unroll
-    for (int pp = 0; pp < NPOS; ++pp) {
-        const int L = p.row(pp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dv[pp][r] = (L >= 0 && 16 * L + p.g + 4 * r < P4) ? rd[16 * L + p.g + 4 * r] : T(0);
-    }
-    const int ntp = (P4 + 15) >> 4;
-#pragma unroll
-    for (int I = 0; I < NBL; ++I) {
-        if (I >= ntp) continue;
-#pragma unroll
-        for (int J = 0; J <= I; ++J) {
-            T acc[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int pp = 0; pp < NPOS; ++pp) {
-                if (I >= Mat::psize(pp)) continue;
-                const int L = p.row(pp);
-                if (L < I || L >= ntp) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rho = p.g + 4 * r;                     // row inside tile row L
-                    T av = E.e[Mat::slot(pp, I)][r], bv = E.e[Mat::slot(pp, J)][r];
-                    if (L == I) av = (p.c < rho) ? av : (p.c == rho ? T(1) : T(0));     // unit lower diagonal tile
-                    if (L == J) bv = (p.c < rho) ? bv : (p.c == rho ? T(1) : T(0));
-                    b.mfma16x16x4(av, bv * dv[pp][r], acc);
-                }
-            }
-            // sum the waves' partial tiles and store -Kaug^-1 where the blob wants it
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[(p.w * 4 + r) * 64 + p.lane] = acc[r];
-            Mat::sync(b);
-            for (int e = b.tid; e < 256; e += NT) {
-                T sum = 0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sum += red[w * 256 + e];
-                const int i = 16 * I + ((e & 63) >> 4) + 4 * (e >> 6), j = 16 * J + (e & 15);
-                if (j > i || i >= nq) continue;
-                const T val = -sum;
-                if (i < n) {                                           // -K, both triangles
-                    F[lay.Kneg + (size_t)i * n + j] = val;
-                    F[lay.Kneg + (size_t)j * n + i] = val;
-                } else if (j < n) {                                    // -N^T (q x n)
-                    F[lay.NTn + (size_t)(i - n) * n + j] = val;
-                } else {                                               // S11^-1 = -(A block of Kaug^-1), both triangles
-                    F[lay.S11i + (size_t)(i - n) * q + (j - n)] = val;
-                    F[lay.S11i + (size_t)(j - n) * q + (i - n)] = val;
-                }
-            }
-            Mat::sync(b);
-        }
-    }
-    if (b.tid == 0) a.status[qp] = 0;
-}
-
 template <int NBL, int NW, int NS>
 QPX_DEV void ipm_tile_body(const Block& b, const IpmArgs<double>& a, int qp, double* lds)
 {

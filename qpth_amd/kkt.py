@@ -6,6 +6,8 @@ backward (qpth/qp.py:93,150-155): here one HBM blob per QP written by qpx_pre_fa
 are all shared by the batch (un-batched parameters, qpth/util.py:44-50) the blob is built
 once and every workgroup reads the same copy.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -76,8 +78,12 @@ class KKTFactors:
         self.dtype, self.device = Q.dtype, Q.device
         code = _lib.QPX_F64 if Q.dtype == torch.float64 else _lib.QPX_F32
         self.elems = self.lib.factor_elems(code, self.n, self.m, self.q)
-        fits = bool(self.lib.dll.qpx_fits_lds(code, self.n, self.m, self.q))
-        self.shared = B > 1 and fits and _is_shared(Q, B) and _is_shared(G, B) and _is_shared(A, B)
+        # the A/B knob of the library is per host thread and selects the blob layout: remember the value the
+        # factors are built under and re-apply it around every later call on them (autograd runs backward
+        # on its own thread)
+        self.variant = int(self.lib.dll.qpx_get_ipm_variant())
+        share_ok = bool(self.lib.dll.qpx_can_share_factors(code, self.n, self.m, self.q))
+        self.shared = B > 1 and share_ok and _is_shared(Q, B) and _is_shared(G, B) and _is_shared(A, B)
         nblob = 1 if self.shared else B
         self.sfac = 0 if self.shared else self.elems
         self.blob = torch.empty(nblob * self.elems, dtype=Q.dtype, device=Q.device)
@@ -97,6 +103,15 @@ class KKTFactors:
             self._pre_event = torch.cuda.Event()
             self._pre_event.record(torch.cuda.current_stream(self.device))
         return self
+
+    @contextlib.contextmanager
+    def _knob(self):
+        dll = self.lib.dll
+        old = dll.qpx_set_ipm_variant(self.variant)
+        try:
+            yield
+        finally:
+            dll.qpx_set_ipm_variant(old)
 
     # -- error surface of pre_factor_kkt / QPFunction (qp.py:81-85, batch.py:379-386) ------
     def raise_on_failure(self, check_Q_spd=False):
@@ -144,9 +159,10 @@ a non-zero diagonal.
         r.status = self.status
         if stall_policy is None:
             stall_policy = default_stall_policy(B)
-        self.lib.ipm(B, n, m, q, p, h, b if q else None, self.blob, self.sfac, eps, maxIter, notImprovedLim,
-                     stall_policy, r.zhat, r.nu if q else None, r.lam, r.slacks, r.iters, self.status,
-                     r.best_resid, r.trace)
+        with self._knob():
+            self.lib.ipm(B, n, m, q, p, h, b if q else None, self.blob, self.sfac, eps, maxIter, notImprovedLim,
+                         stall_policy, r.zhat, r.nu if q else None, r.lam, r.slacks, r.iters, self.status,
+                         r.best_resid, r.trace)
         return r
 
     # -- factor_kkt + solve_kkt (batch.py:435-470, 349-372) ----------------------------------
@@ -158,8 +174,9 @@ a non-zero diagonal.
         ds = torch.empty(B, m, dtype=dt, device=dev)
         dz = torch.empty(B, m, dtype=dt, device=dev)
         dy = torch.empty(B, q, dtype=dt, device=dev) if q else None
-        self.lib.factor_solve_kkt(B, n, m, q, self.blob, self.sfac, d, self._vec(rx, n), self._vec(rs, m),
-                                  self._vec(rz, m), self._vec(ry, q), dx, ds, dz, dy, self.status)
+        with self._knob():
+            self.lib.factor_solve_kkt(B, n, m, q, self.blob, self.sfac, d, self._vec(rx, n), self._vec(rs, m),
+                                      self._vec(rz, m), self._vec(ry, q), dx, ds, dz, dy, self.status)
         return dx, ds, dz, dy
 
     # -- QPFunctionFn.backward (qp.py:127-182) ------------------------------------------------
@@ -186,8 +203,9 @@ a non-zero diagonal.
         dz = buf(wh or (wG and sG), B, m)                         # dh = -dz (qp.py:161)
         dy = buf(q > 0 and (wb or (wA and sA)), B, q)             # db = -dy (qp.py:166)
         zh, lm, nv = self._vec(zhat, n), self._vec(lam, m), self._vec(nu, q)
-        self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m), nv,
-                          self._vec(dl_dz, n), dQ, None, dG, None, dA, None, self.status, dx, dz, dy)
+        with self._knob():
+            self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m), nv,
+                              self._vec(dl_dz, n), dQ, None, dG, None, dA, None, self.status, dx, dz, dy)
         if wQ and sQ:
             dQ = torch.empty(n, n, dtype=dt, device=dev)
             self.lib.batch_outer(dx, zh, zh, dx, 0.5, dQ)

@@ -19,7 +19,7 @@ timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > $OUT/pytest_gpu.
 tail -15 $OUT/pytest_gpu.log >> $OUT/summary.txt
 fi
 echo "== bench" | tee -a $OUT/summary.txt
-timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" | tee -a $OUT/summary.txt
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" | tee -a $OUT/summary.txt
 cat $OUT/bench.json >> $OUT/summary.txt; tail -5 $OUT/bench.err >> $OUT/summary.txt
 timeout 300 python bench.py --dtype f32 --no-cpu-baseline > $OUT/bench_f32.json 2>> $OUT/bench.err
 cat $OUT/bench_f32.json >> $OUT/summary.txt
@@ -36,4 +36,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
     find /tmp/prof_pmc_$C -name "*.db" | while read f; do python scripts/rocprof_summary.py "$f"; done; } > $PROF/${TAG}_pmc_$C.txt 2>&1
   cat $PROF/${TAG}_pmc_$C.txt >> $OUT/summary.txt
 done
+python scripts/make_traffic_json.py $PROF/${TAG}_pmc_FETCH_SIZE.txt $PROF/${TAG}_pmc_WRITE_SIZE.txt > $PROF/ipm_traffic.json 2>> $OUT/summary.txt
+cat $PROF/ipm_traffic.json >> $OUT/summary.txt
 du -sh $OUT | tee -a $OUT/summary.txt

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""profiles/ipm_traffic.json from the two PMC summaries of scripts/gpu_check.sh:
+    make_traffic_json.py <tag>_pmc_FETCH_SIZE.txt <tag>_pmc_WRITE_SIZE.txt [B n m q dtype] > ipm_traffic.json
+HBM bytes per launch of the PDIPM loop kernel = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; the factor 2 is the
+gfx950 correction of MI355X_MICROARCH.md, "HBM").  The record carries the digest of the kernel sources it was
+measured on; bench.py reports `roofline.traffic` only when that digest is the running build's."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def loop_kernel_mean(path, counter):
+    best = None
+    for line in open(path):
+        if ("k_ipm_tile" in line or "k_ipm_grid" in line or "k_ipm<" in line) and counter in line:
+            f = line.split()
+            i = f.index(counter)
+            n, mean = int(f[i + 1]), float(f[i + 2])
+            if best is None or n > best[0]:
+                best = (n, mean, " ".join(f[:i]))
+    if best is None:
+        raise SystemExit("no loop-kernel row with %s in %s" % (counter, path))
+    return best
+
+
+def main():
+    fetch, write = sys.argv[1], sys.argv[2]
+    cfg = sys.argv[3:8] if len(sys.argv) >= 8 else ["512", "100", "100", "0", "f64"]
+    nf, f_kb, kname = loop_kernel_mean(fetch, "FETCH_SIZE")
+    nw, w_kb, _ = loop_kernel_mean(write, "WRITE_SIZE")
+    from bench import kernel_source_digest
+    rec = {"config": [int(cfg[0]), int(cfg[1]), int(cfg[2]), int(cfg[3]), cfg[4]],
+           "hbm_bytes_per_launch": int(round((2.0 * f_kb + w_kb) * 1024)),
+           "fetch_size_kb": f_kb, "write_size_kb": w_kb, "launches": [nf, nw], "kernel": kname,
+           "kernel_source_digest": kernel_source_digest(),
+           "source": "%s, %s: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes" % (os.path.basename(fetch), os.path.basename(write))}
+    print(json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -157,15 +157,6 @@ template <int NBL, int NW, int NS> int launch_ipm_tile(const IpmArgs<double>& a,
     }
     return QPX_OK;
 }
-template <int NBL, int NW> int launch_prefactor_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void*)
-{
-    for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
-        double* base = reinterpret_cast<double*>(lds.data());
-        run_block(64 * NW, [&](const Block& b) { prefactor_tile_body<NBL, NW>(b, a, qp, base); });
-    }
-    return QPX_OK;
-}
 template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {

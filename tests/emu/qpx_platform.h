@@ -17,6 +17,7 @@
 
 #define QPX_DEV inline
 #define QPX_HD inline
+#define QPX_SCHED_FENCE() ((void)0)
 
 namespace qpx {
 

@@ -175,8 +175,60 @@ def extra():
     case("edge_dup_b2_n8_m10_q0", (Q, p, np.concatenate([G, G], 1), np.concatenate([h, h], 1), A, b))
 
 
+def callers():
+    """Round 2 (run with --callers): the shapes the reference's own callers use, with the
+    parameters SHARED by the batch exactly as the notebooks pass them, and f32/f64 pairs of the prof-linear
+    workload from which the f32 tests take the reference's own f32-vs-f64 error distribution.
+
+      cls_*     example-cls-layer.ipynb cell 3: Q = L L^T + eps I (nCls x nCls, shared), p = the layer input
+                (batched), G (nineq x nCls, shared), h = G z0 + s0 (shared), no equalities; f32 there
+      sudoku_*  example-sudoku.ipynb cell 10: Q = 0.1 I, G = -I, h = 0, A (40 x 64, shared parameter),
+                b = 1 (all shared), p = -puzzle (batched), f64
+      f32pair_* prof-linear.py generator: zhat of the reference in f32 and in f64 on the same QPs
+    """
+    # torch.linalg.lu_factor with more than one thread hangs in this container's MKL for matrices of order
+    # >= 160 (observed: "oneMKL ERROR: Parameter 6 was incorrect on entry to DLASWP", then a dead-lock)
+    torch.set_num_threads(1)
+    r = np.random.RandomState(11)
+    nCls, nineq, B = 2, 200, 32
+    L = np.tril(r.rand(nCls, nCls))
+    Q = L.dot(L.T) + 1e-4 * np.eye(nCls)
+    G = r.uniform(-1, 1, (nineq, nCls))
+    h = G.dot(np.zeros(nCls)) + np.ones(nineq)
+    x = np.maximum(r.randn(B, nCls), 0) * 3.0                       # the relu'd features the layer feeds in as p
+    e = np.zeros(0)
+    dl = r.randn(B, nCls)
+    for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+        o = run_ref(Q, x, G, h, e, e, dl=dl, dtype=dt)
+        save("cls_b32_n2_m200_" + tag, Q=Q, p=x, G=G, h=h, A=e, b=e, **o)
+
+    nx, neq, B = 64, 40, 16
+    Q = 0.1 * np.eye(nx)
+    G = -np.eye(nx)
+    h = np.zeros(nx)
+    A = r.rand(neq, nx)
+    b = np.ones(neq)
+    puzzles = (r.rand(B, nx) < 0.25).astype(np.float64)
+    dl = r.randn(B, nx)
+    o = run_ref(Q, -puzzles, G, h, A, b, dl=dl)
+    save("sudoku_b16_n64_m64_q40_f64", Q=Q, p=-puzzles, G=G, h=h, A=A, b=b, **o)
+
+    def pair(name, B, n, m, q, seed):
+        arrs64 = problems.prof_qp(B, n, m, q, seed, np.float64)
+        arrs32 = problems.prof_qp(B, n, m, q, seed, np.float32)
+        o64 = run_ref(*arrs64, dtype=np.float64)
+        o32 = run_ref(*arrs32, dtype=np.float32)
+        save(name, shape=np.array([B, n, m, q, seed]), input_checksum=checksum(*arrs64),
+             zhat_f64=o64["zhat"], zhat_f32=o32["zhat"])
+
+    pair("f32pair_c2_b32_n100_m100", 32, 100, 100, 0, 3)
+    pair("f32pair_c3_b32_n100_m50_q10", 32, 100, 50, 10, 4)
+
+
 if __name__ == "__main__":
     if "--extra" in sys.argv:
         extra()
+    elif "--callers" in sys.argv:
+        callers()
     else:
         main()

@@ -194,8 +194,8 @@ def test_batch_of_one_uses_the_reference_stall_counter():
 
 # every form of the loop kernel the dispatcher can pick (include/qpx.h, qpx_set_ipm_variant):
 # 1 = workgroup kernels, 2 = wave kernel, +256 / +512 = 16x16 / 8x8 thread grid, +1024 = matrix-core
-# tiles with 1 / 2 / 4 waves per QP (+2048 / +4096 / +8192); 16384 = tile pre-factorisation (opt-in)
-LOOP_FORMS = [1, 256, 512, 1024 + 2048, 1024 + 4096, 1024 + 8192, 16384]
+# tiles with 1 / 2 / 4 waves per QP (+2048 / +4096 / +8192)
+LOOP_FORMS = [1, 256, 512, 1024 + 2048, 1024 + 4096, 1024 + 8192]
 
 
 @pytest.mark.parametrize("variant", LOOP_FORMS)
@@ -277,3 +277,78 @@ def test_edge_shapes_match_the_reference(name):
     for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
         if k in g and gr is not None and not ("dup" in name and k in ("dG", "dh")):
             assert np.abs(gr - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
+
+
+# ---------------------------------------------------------------- round 2: host logic around the new C-ABI arguments
+@pytest.mark.parametrize("name", ["c3s_b4_n20_m10_q4_f64", "broadcast_b5_n12_m9_q3"])
+def test_backward_from_external_solutions(name):
+    """QPSolvers.CVXPY (qp.py:97-120,142-155): forward = an external solver's (zhat, nu, lam, slacks) -- the
+    reference's own, replayed from the golden file -- backward = qpx_backward on rebuilt factors (ctx.fac None)."""
+    from qpth_amd.qp import QPSolvers
+    from qpth_amd.solvers import external
+    g = load_golden(name)
+    arrs = [g[k] for k in ("Q", "p", "G", "h", "A", "b")]
+    calls = []
+
+    def replay(Q, p, G, h, A, b):
+        i = len(calls)
+        calls.append(i)
+        return g["zhat"][i], (g["nu"][i] if g["nu"].shape[1] else None), g["lam"][i], g["slacks"][i]
+
+    external.set_solver(replay)
+    try:
+        tq = tens(arrs)
+        with emulated():
+            z = QPFunction(verbose=-1, solver=QPSolvers.CVXPY)(*tq)
+            z.backward(torch.tensor(g["dl_dz"]))
+    finally:
+        external.set_solver(None)
+    assert len(calls) == g["zhat"].shape[0]
+    assert np.array_equal(z.detach().numpy(), g["zhat"])
+    for k, t in zip(("dQ", "dp", "dG", "dh", "dA", "db"), tq):
+        if k in g:
+            assert t.grad.shape == g[k].shape, k
+            assert np.abs(t.grad.numpy() - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
+
+
+def test_external_solver_without_cvxpy_fails_loudly():
+    from qpth_amd.qp import QPSolvers
+    arrs = problems.prof_qp(1, 4, 3, 0, seed=1)
+    with emulated():
+        with pytest.raises(RuntimeError, match="cvxpy"):
+            QPFunction(verbose=-1, solver=QPSolvers.CVXPY)(*tens(arrs, grad=False))
+
+
+def test_needs_input_grad_is_honoured():
+    """Only the gradients autograd asks for are computed (NULL outputs of qpx_backward)."""
+    arrs = problems.prof_qp(3, 12, 9, 3, seed=2)
+    dl = np.random.RandomState(2).randn(3, 12)
+    _, full = run_qpf(arrs, dl)
+    for only in (1, 3, 2, 4):
+        tq = tens(arrs, grad=False)
+        tq[only].requires_grad_(True)
+        with emulated():
+            z = QPFunction(verbose=-1)(*tq)
+            z.backward(torch.tensor(dl))
+        for i, t in enumerate(tq):
+            assert (t.grad is not None) == (i == only)
+        assert np.array_equal(tq[only].grad.numpy(), full[only])
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_shared_parameter_gradients_are_one_contraction(dtype):
+    """Q, G, A shared by the batch: one factor blob, gradients = the batch mean (qp.py:159-177) formed by
+    qpx_batch_outer (an MFMA contraction over the batch in both dtypes) instead of B outer products."""
+    from qpth_amd.kkt import KKTFactors
+    g = load_golden("broadcast_b5_n12_m9_q3")
+    arrs = [g[k] for k in ("Q", "p", "G", "h", "A", "b")]
+    z, grads = run_qpf(arrs, g["dl_dz"], dtype=dtype)
+    tol = 1e-6 if dtype == torch.float64 else 2e-3
+    assert np.abs(z - g["zhat"]).max() < tol * max(1.0, np.abs(g["zhat"]).max())
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        assert gr.shape == g[k].shape, k
+        assert np.abs(gr - g[k]).max() <= 10 * tol * max(1.0, np.abs(g[k]).max()), k
+    tq = tens(arrs, dtype, grad=False)
+    with emulated():
+        fac = KKTFactors.build(tq[0], tq[2], tq[4], nBatch=5)
+    assert fac.shared and fac.blob.numel() == fac.elems

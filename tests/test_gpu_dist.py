@@ -1,0 +1,73 @@
+"""-m gpu: the multi-GPU path over RCCL (backend "nccl") on however many MI355X are visible -- batch shards per
+rank, zhat all_gathered, shared-parameter gradient all_reduced to the global mean.  The same
+code is covered on CPU by tests/test_dist_gloo.py (gloo, world_size 2).  With one visible GPU the test SKIPS (and
+says so): a single-device run proves nothing about RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import problems
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from qpth_amd import dist as qdist
+    from qpth_amd.qp import QPFunction
+    nB, n, m, q = 64 * world + 3, 30, 20, 4                    # uneven shards on purpose
+    Q, p, G, h, A, b = problems.prof_qp(nB, n, m, q, seed=9)
+    Qs = torch.tensor(Q[0], device=dev, requires_grad=True)    # shared by the batch: every rank holds it
+    tp = torch.tensor(p, device=dev, requires_grad=True)
+    tG, th, tA, tb = [torch.tensor(x, device=dev) for x in (G, h, A, b)]
+    lo, hi = qdist.shard_bounds(nB, rank, world)
+    z_local, z_full = qdist.solve_sharded(QPFunction(verbose=-1), Qs, tp, tG, th, tA, tb, nB)
+    z_local.backward(torch.ones_like(z_local))
+    dQ = qdist.reduce_shared_grad(Qs.grad, hi - lo, nB)
+    dp_full = tp.grad.clone()
+    dist.all_reduce(dp_full, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "out.npz"), z=z_full.cpu().numpy(), dQ=dQ.cpu().numpy(), dp=dp_full.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_batch_sharding(tmp_path):
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("RCCL PATH NOT EXERCISED: %d GPU visible on this box (needs >= 2)" % world)
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    out = np.load(tmp_path / "out.npz")
+    # the same global batch on one device, shared Q
+    from qpth_amd.qp import QPFunction
+    dev = torch.device("cuda:0")
+    nB, n, m, q = 64 * world + 3, 30, 20, 4
+    Q, p, G, h, A, b = problems.prof_qp(nB, n, m, q, seed=9)
+    Qs = torch.tensor(Q[0], device=dev, requires_grad=True)
+    tp = torch.tensor(p, device=dev, requires_grad=True)
+    z = QPFunction(verbose=-1)(Qs, tp, *[torch.tensor(x, device=dev) for x in (G, h, A, b)])
+    z.backward(torch.ones_like(z))
+    assert rel_err(out["z"], z.detach().cpu().numpy()).max() < 1e-9
+    assert np.abs(out["dQ"] - Qs.grad.cpu().numpy()).max() < 1e-9 * max(1.0, Qs.grad.abs().max().item())
+    assert np.abs(out["dp"] - tp.grad.cpu().numpy()).max() < 1e-9 * max(1.0, tp.grad.abs().max().item())
