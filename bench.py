@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--shared", action="store_true",
                     help="Q, G, A shared by the batch (SURVEY 8f-1): one pre-factorisation for the whole batch, "
                          "shared-parameter gradients reduced by qpx_batch_outer (+ all_reduce at N > 1)")
+    ap.add_argument("--refine", type=int, default=None,
+                    help="QPFunction(refine=...): finishing iterations on the residuals of the original data (default: "
+                         "automatic = 3 in float32, 0 in float64; 0 = the loop kernel alone)")
     ap.add_argument("--table", default=None, choices=["prof-linear", "prof-gurobi"])
     args = ap.parse_args()
 
@@ -240,7 +243,7 @@ def main():
         tG.requires_grad_(True)
     tp.requires_grad_(True)                      # prof-linear.py:99
     ones = torch.ones(B, n, dtype=tQ.dtype, device=dev)
-    qpf = QPFunction(verbose=-1)
+    qpf = QPFunction(verbose=-1, refine=args.refine)
     gather = distributed and not args.no_gather
 
     def step():
@@ -378,9 +381,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s fwd+bwd: batch=%d nz=%d nineq=%d neq=%d %s, dense random QP (prof-linear.py "
-                                   "generator)%s, QPFunction(verbose=-1) defaults, p requires grad%s"
+                                   "generator)%s, QPFunction(verbose=-1%s) defaults, p requires grad%s"
                                    % (names[args.config], Bcfg, n, m, q, "GLOBAL (sharded)" if strong else "per GPU",
                                       ", Q G A shared by the batch" if args.shared else "",
+                                      "" if args.refine is None else ", refine=%d" % args.refine,
                                       ", zhat all_gathered over RCCL" if gather else ""),
                        "global_batch": global_B, "parallelism": "batch-sharded x%d" % world,
                        "ipm_iterations_mean": iters_mean, "ipm_iterations_max": int(iters.max()),

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define QPX_ABI_VERSION 2
+#define QPX_ABI_VERSION 3
 
 enum { QPX_F32 = 0, QPX_F64 = 1 };
 
@@ -85,7 +85,9 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
 /* tuning/A-B knob (per host thread): which kernel family runs.  0 (default) = automatic: the thread-grid /
  * matrix-core kernels (sweep pre-factorisation, register-resident LDL^T with in-place inverse factor)
  * whenever nz+neq+nineq <= 208, else one 256-thread workgroup per QP with the matrices in LDS
- * (or in HBM when they do not fit); 1 = always the workgroup kernels.
+ * (neq > 0; for neq = 0 sizes whose matrices do not fit in LDS -- BASELINE.json configs[3], nz = nineq = 500 -- run
+ * through the large-QP family: batched multi-kernel blocked Cholesky / MFMA GEMM path, qpx_big.h);
+ * 1 = always the workgroup kernels; 3 = the large-QP family whenever neq = 0.
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4; by default the library picks by dtype, size and batch.
@@ -124,21 +126,29 @@ int qpx_forward(int dtype, int B, int n, int m, int q,
                 int32_t* iters, int32_t* status, void* best_resid, void* trace, qpx_stream_t stream);
 
 /* factor_kkt(S_LU, R, d) then solve_kkt(Q_LU, d, G, A, S_LU, rx, rs, rz, ry) -> dx, ds, dz, dy.
- * d (B,m) > 0; rx (B,n), rs, rz (B,m), ry (B,q): NULL means zeros; dy may be NULL when q = 0. */
+ * d (B,m) > 0; rx (B,n), rs, rz (B,m), ry (B,q): NULL means zeros; dy may be NULL when q = 0.
+ * refine > 0: that many steps of ITERATIVE REFINEMENT on the residual of the original KKT system
+ * (qpth/solvers/pdipm/batch.py:228-270, kkt_resid_reg + solve_kkt_ir -- KKTSolvers.IR_UNOPT), evaluated with the
+ * caller's Q (sQ), G (sG), A (sA) (batch strides in elements, 0 = shared); the factorisation is re-used, not repeated.
+ * Implemented by the thread-grid / tile kernels (nz+neq+nineq <= 208); the other families ignore it. */
 int qpx_factor_solve_kkt(int dtype, int B, int n, int m, int q, void* factors, int64_t sfac,
                          const void* d, const void* rx, const void* rs, const void* rz, const void* ry,
-                         void* dx, void* ds, void* dz, void* dy, int32_t* status, qpx_stream_t stream);
+                         void* dx, void* ds, void* dz, void* dy,
+                         int refine, const void* Q, int64_t sQ, const void* G, int64_t sG, const void* A, int64_t sA,
+                         int32_t* status, qpx_stream_t stream);
 
 /* QPFunctionFn.backward for given (zhat, lam, slacks, nu) -- from qpx_ipm or from any other
  * solver (qp.py:142-155) -- and dl_dz (B,n).  Per-QP gradients dQ (B,n,n), dp (B,n),
  * dG (B,m,n), dh (B,m), dA (B,q,n), db (B,q); each of the six may be NULL = "this gradient is not
  * wanted" (ctx.needs_input_grad): nothing is computed or written for it.  dx (B,n), dz (B,m),
  * dy (B,q): optional (NULL = skip) solution of the backward KKT system itself (qp.py:151-155), the
- * inputs of qpx_batch_outer. */
+ * inputs of qpx_batch_outer.  refine, Q, G, A: as for qpx_factor_solve_kkt (0 / NULL: no refinement). */
 int qpx_backward(int dtype, int B, int n, int m, int q, void* factors, int64_t sfac,
                  const void* zhat, const void* lam, const void* slack, const void* nu, const void* dl_dz,
                  void* dQ, void* dp, void* dG, void* dh, void* dA, void* db,
-                 void* dx, void* dz, void* dy, int32_t* status, qpx_stream_t stream);
+                 void* dx, void* dz, void* dy,
+                 int refine, const void* Q, int64_t sQ, const void* G, int64_t sG, const void* A, int64_t sA,
+                 int32_t* status, qpx_stream_t stream);
 
 /* Batch-MEAN of the gradient of a parameter that the whole batch shares (qp.py:159-177: the reference
  * forms B outer products and then `.mean(0)`): one contraction over the batch instead,

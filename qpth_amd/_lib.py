@@ -39,9 +39,9 @@ _SIGNATURES = {
     "qpx_forward": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                          _vp, _i64, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qpx_factor_solve_kkt": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                  _vp, _vp]),
+                                  _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "qpx_backward": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                          _vp, _vp, _vp, _vp, _vp, _vp]),
+                          _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "qpx_batch_outer": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp]),
 }
 ABI_SYMBOLS = tuple(_SIGNATURES)
@@ -98,7 +98,7 @@ class QpxLib:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(self.dll, name)       # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if self.dll.qpx_abi_version() != 2:
+        if self.dll.qpx_abi_version() != 3:
             raise RuntimeError("qpth_amd: ABI version mismatch in %s" % path)
 
     def check(self, code):
@@ -137,19 +137,24 @@ class QpxLib:
             _ptr(slack), _ptr(iters), _ptr(status), _ptr(best_resid), _ptr(trace), _stream(factors)))
 
     # -- batch.py:435-470 + 349-372 ------------------------------------------------------
-    def factor_solve_kkt(self, B, n, m, q, factors, sfac, d, rx, rs, rz, ry, dx, ds, dz, dy, status):
+    def factor_solve_kkt(self, B, n, m, q, factors, sfac, d, rx, rs, rz, ry, dx, ds, dz, dy, status,
+                         refine=0, Q=None, G=None, A=None):
+        Qp, Gp, Ap = Param(Q, 3), Param(G, 3), Param(A, 3)
         self.check(self.dll.qpx_factor_solve_kkt(
             _dtype_code(factors), B, n, m, q, _ptr(factors), int(sfac), _ptr(d), _ptr(rx), _ptr(rs), _ptr(rz),
-            _ptr(ry), _ptr(dx), _ptr(ds), _ptr(dz), _ptr(dy), _ptr(status), _stream(factors)))
+            _ptr(ry), _ptr(dx), _ptr(ds), _ptr(dz), _ptr(dy), int(refine), Qp.ptr, Qp.stride, Gp.ptr, Gp.stride,
+            Ap.ptr, Ap.stride, _ptr(status), _stream(factors)))
 
     # -- qp.py:127-182 --------------------------------------------------------------------
     def backward(self, B, n, m, q, factors, sfac, zhat, lam, slack, nu, dl_dz, dQ, dp, dG, dh, dA, db, status,
-                 dx=None, dz=None, dy=None):
+                 dx=None, dz=None, dy=None, refine=0, Q=None, G=None, A=None):
         """Any of dQ..db may be None (gradient not wanted); dx, dz, dy: optional KKT solution outputs."""
+        Qp, Gp, Ap = Param(Q, 3), Param(G, 3), Param(A, 3)
         self.check(self.dll.qpx_backward(
             _dtype_code(factors), B, n, m, q, _ptr(factors), int(sfac), _ptr(zhat), _ptr(lam), _ptr(slack),
             _ptr(nu), _ptr(dl_dz), _ptr(dQ), _ptr(dp), _ptr(dG), _ptr(dh), _ptr(dA), _ptr(db),
-            _ptr(dx), _ptr(dz), _ptr(dy), _ptr(status), _stream(factors)))
+            _ptr(dx), _ptr(dz), _ptr(dy), int(refine), Qp.ptr, Qp.stride, Gp.ptr, Gp.stride, Ap.ptr, Ap.stride,
+            _ptr(status), _stream(factors)))
 
     # -- qp.py:159-177, the `.mean(0)` of a shared parameter's gradient as one contraction over the batch
     def batch_outer(self, u, v, w, x, scale, out):

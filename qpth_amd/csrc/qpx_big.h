@@ -1,0 +1,687 @@
+// qpx_big.h -- the LARGE-QP kernel family (BASELINE.json configs[3]: batch 128, nz = nineq = 500).
+//
+// At this size one QP's matrices are 2 MB each: they live in HBM / L2, a QP is worked on by MANY workgroups,
+// and the dense contractions are real GEMMs -- so the forward is a stream-ordered SEQUENCE of batched kernels
+// (every launch covers the whole batch; no host synchronisation), not one kernel per QP:
+//
+//   pre-factorisation (pre_factor_kkt, batch.py:375-429), neq = 0:
+//     Lq   = chol(Q)                      blocked right-looking Cholesky: panel kernel + MFMA trailing update
+//     Zt   = G Lq^-T   (nineq x nz)       blocked triangular solve: panel kernel + MFMA trailing update
+//     R    = Zt Zt^T = G Q^-1 G^T         one MFMA GEMM (the reference's R, batch.py:396-399)
+//   PDIPM loop (batch.py:47-207), the condensed iteration of ipm_loop_body (qpx_grid.h) with its vectors in HBM:
+//     per pass: R z' (row-dot kernel), wave-0 vector work (phase kernels), T = R + diag(s/z) factored by the
+//     same blocked Cholesky, two solves = four blocked triangular substitutions
+//   backward (qp.py:127-182): one factorisation + one solve + the outer products.
+//
+// Blocks are 64 x 64; every matrix is stored square, row-major, padded to a multiple of 64 (identity padding on
+// the diagonal).  A factor keeps L in the lower triangle and L^T in the upper one (both substitutions then read
+// ROWS, coalesced) and the inverses of its diagonal blocks W_kk = L_kk^-1 beside it: a diagonal-block solve is a
+// 64 x 64 mat-vec, and the panel operation X W_kk^T has independent outputs (four threads per row).
+// The trailing updates C -= A B^T run on v_mfma_f64_16x16x4 (f32: v_mfma_f32_16x16x4): a workgroup owns a 64 x 64
+// tile of C, each of its four waves a 32 x 32 quadrant (four accumulator tiles), operands staged through LDS.
+#pragma once
+#include "qpx_grid.h"
+
+namespace qpx {
+
+constexpr int kBB = 64;          // block order
+constexpr int kBL = kBB + 2;     // LDS row stride of a staged block (elements): 2-way bank conflicts at most
+QPX_LAYOUT_HD int big_pad(int x) { return (x + kBB - 1) / kBB * kBB; }
+
+// per-QP vectors of the loop (each VP = max(NP, MP) elements), same roles as in ipm_loop_body
+enum BigVec {
+    bvP, bvU, bvC, bvR1, bvZ, bvS, bvA, bvB, bvD, bvBZ, bvBS, bvRH, bvX, bvDZA, bvDSA, bvRSC, bvRZ, bvRS, bvW, bvY,
+    bvONE, bvCount
+};
+enum BigScal { bsTau = 0, bsBtau, bsSigz, bsSigs, bsBres, bsFeasPrev, bsAlphaPrev, bsMu, bsSzdot, bsGt1 = 15 };
+enum BigCtrl { bcStop = 0, bcNnot, bcFloor, bcSt, bcIters, bcFail };
+
+struct BigLayout {
+    size_t Lq, Wq, Zt, R, T, Wt, vec, scal, ctrl, total;
+    int NP, MP, VP;
+    QPX_LAYOUT_HD size_t v(int i) const { return vec + (size_t)i * VP; }
+};
+QPX_LAYOUT_HD BigLayout big_layout(int n, int m)
+{
+    BigLayout L;
+    L.NP = big_pad(n); L.MP = big_pad(m); L.VP = L.NP > L.MP ? L.NP : L.MP;
+    size_t o = 0;
+    L.Lq = o;  o += (size_t)L.NP * L.NP;
+    L.Wq = o;  o += (size_t)(L.NP / kBB) * 2 * kBB * kBB;      // per diagonal block: W_kk, then W_kk^T
+    L.Zt = o;  o += (size_t)L.MP * L.NP;
+    L.R = o;   o += (size_t)L.MP * L.MP;
+    L.T = o;   o += (size_t)L.MP * L.MP;
+    L.Wt = o;  o += (size_t)(L.MP / kBB) * 2 * kBB * kBB;
+    L.vec = o; o += (size_t)bvCount * L.VP;
+    L.scal = o; o += 16;
+    L.ctrl = o; o += 16;
+    L.total = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------ pack
+template <class T> struct BigPackArgs {
+    int B, rows, cols, P, ldp, sym;       // source rows x cols -> destination P x ldp (sym: symmetrise, identity padding)
+    const T* src; long long ssrc;
+    T* dst; size_t sdst;
+};
+// grid (B, P / 16): 16 destination rows per workgroup
+template <class T> QPX_DEV void big_pack_body(const Block& b, const BigPackArgs<T>& a, int qp, int chunk)
+{
+    const T* S = a.src + (size_t)qp * a.ssrc;
+    T* D = a.dst + (size_t)qp * a.sdst;
+    for (int e = b.tid; e < 16 * a.ldp; e += b.nt) {
+        const int i = 16 * chunk + e / a.ldp, j = e % a.ldp;
+        if (i >= a.P) continue;
+        T v = T(0);
+        if (i < a.rows && j < a.cols) v = a.sym ? T(0.5) * (S[(size_t)i * a.cols + j] + S[(size_t)j * a.cols + i]) : S[(size_t)i * a.cols + j];
+        else if (a.sym && i == j) v = T(1);
+        D[(size_t)i * a.ldp + j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ diagonal block
+// The diagonal block D = M[k][k] of a panel step (Ms + diag at the first step of T = R + diag), one workgroup per QP:
+// the 64 x 64 block is held by a 16 x 16 thread grid in registers and eliminated by grid_ldl_inv (qpx_grid.h, the
+// routine of the thread-grid loop kernels): D = L~ diag(d) L~^T with W~ = L~^-1 built in place, 1/d in LDS.  Written:
+//   W_kk = L_kk^-1 = diag(d^-1/2) W~   (L_kk = L~ diag(d^1/2) is the Cholesky factor)   and its transpose,
+// 2 x 64 x 64 elements per block.  Nothing downstream reads the diagonal block of the factor itself: the panel
+// below it becomes X W_kk^T (a GEMM, big_gemm_body) and the substitutions multiply by W_kk / W_kk^T.
+template <class T> struct BigPanelArgs {
+    int B, k;
+    const T* M; size_t sM; int ld;        // source of the block (T, or R at the first step)
+    const T* dg; size_t sdg;              // first-step diagonal (added) or null
+    T* W; size_t sW;                      // W blocks out
+    int* ctrl; size_t sctrl;              // per-QP control words (elements of int); may be null
+    int fail_bit;                         // status bit OR-ed into ctrl[bcFail] when a pivot breaks down
+    int check_stop;                       // skip QPs whose ctrl[bcStop] is set (loop factorisations)
+};
+QPX_LAYOUT_HD size_t big_panel_lds_elems() { return (size_t)3 * kBB + 8; }
+
+template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArgs<T>& a, int qp, T* lds)
+{
+    int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
+    if (a.check_stop && ctrl && ctrl[bcStop]) return;
+    constexpr int GS = 16, NBL = kBB / GS;
+    const GridPos<GS> g(b);
+    T* vec2 = lds;                // 2 x 64: published column / row of a pivot step
+    T* dsl = vec2 + 2 * kBB;      // pivots
+    T* rd = dsl + 8;              // 1 / d_k
+    const T* M = a.M + (size_t)qp * a.sM;
+    const int k0 = a.k * kBB;
+    T E[gtri(NBL)];
+#pragma unroll
+    for (int li = 0; li < NBL; ++li)
+#pragma unroll
+        for (int lj = 0; lj <= li; ++lj) {
+            const int i = GS * li + g.a, j = GS * lj + g.b;
+            T v = M[(size_t)(k0 + i) * a.ld + k0 + j];
+            if (a.dg && i == j) v += a.dg[(size_t)qp * a.sdg + k0 + i];
+            E[gidx(li, lj)] = v;
+        }
+    GridPos<GS>::sync(b);
+    const bool ok = grid_ldl_inv<T, GS, NBL>(b, g, E, vec2, dsl, rd, kBB);
+    if (!ok) {
+        if (b.tid == 0 && ctrl) ctrl[bcFail] |= a.fail_bit;
+        return;
+    }
+    T* W = a.W + (size_t)qp * a.sW + (size_t)a.k * 2 * kBB * kBB;
+    T* Wt = W + kBB * kBB;
+#pragma unroll
+    for (int li = 0; li < NBL; ++li)
+#pragma unroll
+        for (int lj = 0; lj < NBL; ++lj) {
+            const int i = GS * li + g.a, j = GS * lj + g.b;
+            T v = T(0);
+            if (lj <= li) {
+                const T rs = sqrt_(rd[i]);
+                v = (j < i) ? E[gidx(li, lj)] * rs : (j == i ? rs : T(0));
+            }
+            W[i * kBB + j] = v;
+            Wt[j * kBB + i] = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------ GEMM tile
+// C[tile (ti, tj)] = (Cs or C or 0)[tile] (+ diag) + alpha * sum over kb < nk of A[arb0+ti][akb0+kb] B[brb0+tj][bkb0+kb]^T
+// grid (B, nti * ntj); lower: tiles with cb0 + ... row block < column block are skipped; mirror: the tile is also
+// written transposed (symmetric result stored in full).
+template <class T> struct BigGemmArgs {
+    int B, nti, ntj, crb0, ccb0, arb0, brb0, akb0, bkb0, nk, lower, mirror, zero_init;
+    T* C; size_t sC; int ldc;
+    const T* Cs; size_t sCs; int ldcs;
+    const T* dg; size_t sdg;
+    const T* A; size_t sA; int lda;
+    const T* Bm; size_t sB; int ldb;
+    T alpha;
+    const int* ctrl; size_t sctrl; int check_stop;
+};
+QPX_LAYOUT_HD size_t big_gemm_lds_elems() { return (size_t)2 * kBB * kBL; }
+
+template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<T>& a, int qp, int tile, T* lds)
+{
+    if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
+    const int ti = tile / a.ntj, tj = tile - ti * a.ntj;
+    const int crb = a.crb0 + ti, ccb = a.ccb0 + tj;
+    if (a.lower && crb < ccb) return;
+    T* As = lds;                 // [k][row]  (k-major: the MFMA operand of lane (g, c) is As[4 s + g][c + 16 rt])
+    T* Bs = As + kBB * kBL;
+    const T* Ag = a.A + (size_t)qp * a.sA + (size_t)(a.arb0 + ti) * kBB * a.lda;
+    const T* Bg = a.Bm + (size_t)qp * a.sB + (size_t)(a.brb0 + tj) * kBB * a.ldb;
+    const int lane = b.lane(), w = b.uniform(b.wave()), g = lane >> 4, c16 = lane & 15;
+    const int qr = (w >> 1) * 32, qc = (w & 1) * 32;         // this wave's 32 x 32 quadrant
+    T acc[2][2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[x][y][r] = T(0);
+    for (int kb = 0; kb < a.nk; ++kb) {
+        b.sync();
+        for (int e = b.tid; e < kBB * kBB; e += b.nt) {
+            const int r = e >> 6, kk = e & 63;
+            As[kk * kBL + r] = Ag[(size_t)r * a.lda + (a.akb0 + kb) * kBB + kk];
+            Bs[kk * kBL + r] = Bg[(size_t)r * a.ldb + (a.bkb0 + kb) * kBB + kk];
+        }
+        b.sync();
+#pragma unroll 4
+        for (int s = 0; s < kBB / 4; ++s) {
+            const T a0 = As[(4 * s + g) * kBL + qr + c16], a1 = As[(4 * s + g) * kBL + qr + 16 + c16];
+            const T b0 = Bs[(4 * s + g) * kBL + qc + c16], b1 = Bs[(4 * s + g) * kBL + qc + 16 + c16];
+            b.mfma16x16x4(a0, b0, acc[0][0]);
+            b.mfma16x16x4(a0, b1, acc[0][1]);
+            b.mfma16x16x4(a1, b0, acc[1][0]);
+            b.mfma16x16x4(a1, b1, acc[1][1]);
+        }
+    }
+    T* C = a.C + (size_t)qp * a.sC;
+    const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs : C;
+    const int ldcs = a.Cs ? a.ldcs : a.ldc;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = crb * kBB + qr + 16 * x + Block::mfma_row(T(0), g, r), j = ccb * kBB + qc + 16 * y + c16;
+                T v = a.zero_init ? T(0) : Cs[(size_t)i * ldcs + j];
+                if (a.dg && i == j) v += a.dg[(size_t)qp * a.sdg + i];
+                v = fma_(a.alpha, acc[x][y][r], v);
+                C[(size_t)i * a.ldc + j] = v;
+                if (a.mirror && crb != ccb) C[(size_t)j * a.ldc + i] = v;
+            }
+}
+
+// ------------------------------------------------------------------------------------------ triangular solve
+// x <- L^-1 xin (dir 0) or x <- L^-T xin (dir 1) for one QP per workgroup, by blocks of 64, every lane a ROW of the
+// block so that nothing is reduced across lanes: for the forward direction the known entries c multiply column c
+// of L, i.e. row c of the L^T copy in the upper triangle (64 consecutive elements per wave load); for the backward
+// direction row j of L itself.  The four waves split the known entries and add their partial sums through LDS; the
+// diagonal block is a mat-vec with W_kk (its transpose), read from the copy whose rows are the contiguous ones.
+template <class T> struct BigTrsvArgs {
+    int B, nb, dir, post;
+    const T* M; size_t sM; int ld;
+    const T* W; size_t sW;
+    const T* xin; size_t sxin;            // right-hand side (may be the same array as x)
+    T* x; size_t sx;
+    const int* ctrl; size_t sctrl; int check_stop;
+};
+QPX_LAYOUT_HD size_t big_trsv_lds_elems(int np) { return (size_t)np + 5 * kBB; }
+
+template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<T>& a, int qp, T* lds)
+{
+    if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
+    const int np = a.nb * kBB;
+    T* xs = lds;                 // the vector
+    T* part = xs + np;           // 4 x 64 partial sums
+    T* t = part + 4 * kBB;       // block right-hand side
+    const T* M = a.M + (size_t)qp * a.sM;
+    T* x = a.x + (size_t)qp * a.sx;
+    const T* xin = a.xin + (size_t)qp * a.sxin;
+    for (int i = b.tid; i < np; i += b.nt) xs[i] = xin[i];
+    const int lane = b.lane(), w = b.uniform(b.wave());
+    for (int kk = 0; kk < a.nb; ++kk) {
+        const int k = a.dir == 0 ? kk : a.nb - 1 - kk;
+        const int k0 = k * kBB;
+        const int c0 = a.dir == 0 ? 0 : k0 + kBB, c1 = a.dir == 0 ? k0 : np;      // known entries
+        b.sync();
+        {
+            // rows c of the stored matrix (L^T above the diagonal for dir 0, L below it for dir 1), element k0 + lane
+            const T* col = M + k0 + lane;
+            T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int c = c0 + w;
+            for (; c + 12 < c1; c += 16) {
+                const T m0 = col[(size_t)c * a.ld], m1 = col[(size_t)(c + 4) * a.ld];
+                const T m2 = col[(size_t)(c + 8) * a.ld], m3 = col[(size_t)(c + 12) * a.ld];
+                a0 = fma_(m0, xs[c], a0);
+                a1 = fma_(m1, xs[c + 4], a1);
+                a2 = fma_(m2, xs[c + 8], a2);
+                a3 = fma_(m3, xs[c + 12], a3);
+            }
+            for (; c < c1; c += 4) a0 = fma_(col[(size_t)c * a.ld], xs[c], a0);
+            part[w * kBB + lane] = (a0 + a1) + (a2 + a3);
+        }
+        b.sync();
+        if (b.tid < kBB) t[b.tid] = xs[k0 + b.tid] - ((part[b.tid] + part[kBB + b.tid]) + (part[2 * kBB + b.tid] + part[3 * kBB + b.tid]));
+        b.sync();
+        {
+            // x_k = W t (dir 0: rows of W^T are the contiguous ones) or W^T t (dir 1: rows of W)
+            const T* Wg = a.W + (size_t)qp * a.sW + (size_t)k * 2 * kBB * kBB + (a.dir == 0 ? kBB * kBB : 0) + lane;
+            T acc = 0;
+#pragma unroll 4
+            for (int c = w; c < kBB; c += 4) acc = fma_(Wg[c * kBB], t[c], acc);
+            part[w * kBB + lane] = acc;
+        }
+        b.sync();
+        if (b.tid < kBB) xs[k0 + b.tid] = (part[b.tid] + part[kBB + b.tid]) + (part[2 * kBB + b.tid] + part[3 * kBB + b.tid]);
+    }
+    b.sync();
+    for (int i = b.tid; i < np; i += b.nt) x[i] = a.post ? -xs[i] : xs[i];
+}
+
+// ------------------------------------------------------------------------------------------ mat-vec
+// y[i] = beta y0[i] + alpha sum_j Mt[i][j] x[j]   (trans 0: rows of M; trans 1: y[j] = ... sum_i M[i][j] x[i])
+// grid (B, ceil(out / 64)): 64 outputs per workgroup.  rows/cols are the logical extent that is read.
+template <class T> struct BigGemvArgs {
+    int B, rows, cols, trans;
+    const T* M; size_t sM; int ld;
+    const T* x; size_t sx;
+    const T* y0; size_t sy0;
+    T* y; size_t sy;
+    T alpha, beta;
+    const int* ctrl; size_t sctrl; int check_stop;
+};
+template <class T> QPX_DEV void big_gemv_body(const Block& b, const BigGemvArgs<T>& a, int qp, int chunk, T* lds)
+{
+    if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
+    const T* M = a.M + (size_t)qp * a.sM;
+    const T* x = a.x + (size_t)qp * a.sx;
+    const T* y0 = a.y0 ? a.y0 + (size_t)qp * a.sy0 : nullptr;
+    T* y = a.y + (size_t)qp * a.sy;
+    const int lane = b.lane(), w = b.uniform(b.wave()), nw = b.nwaves();
+    if (!a.trans) {
+        for (int r = w; r < kBB; r += nw) {
+            const int i = chunk * kBB + r;
+            if (i >= a.rows) break;
+            const T* row = M + (size_t)i * a.ld;
+            T acc = T(0);
+            for (int c = lane; c < a.cols; c += kWave) acc = fma_(row[c], x[c], acc);
+            acc = wave_sum(b, acc);
+            if (lane == 0) y[i] = fma_(a.alpha, acc, y0 ? a.beta * y0[i] : T(0));
+        }
+    } else {
+        // 64 output columns, the rows dealt over the four waves, partial sums combined through LDS
+        const int j = chunk * kBB + lane;
+        T acc = T(0);
+        if (j < a.cols)
+            for (int i = w; i < a.rows; i += nw) acc = fma_(M[(size_t)i * a.ld + j], x[i], acc);
+        lds[w * kWave + lane] = acc;
+        b.sync();
+        if (w == 0 && j < a.cols) {
+            T s = T(0);
+            for (int ww = 0; ww < nw; ++ww) s += lds[ww * kWave + lane];
+            y[j] = fma_(a.alpha, s, y0 ? a.beta * y0[j] : T(0));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ loop phases
+// The vector work of the PDIPM loop: one wave per QP on the blob's vectors (NS = MP / 64 register slots).  The
+// mathematics and the control flow are those of ipm_loop_body (qpx_grid.h), phase by phase:
+//   0  initialise the state (z = s = 1, tau = 1, ...), stage p and c's constant part
+//   1  start point: x = -T^-1 c is in vX -> shifts, z, s, best := start, vA = z'
+//   2  residuals with vB = R z', best iterate, stop decision, d = s/z, affine right-hand side
+//   3  affine step in vX -> step length, sigma, corrector right-hand side
+//   4  corrector step in vX -> step length, update z, s, tau, vA = z'
+//   5  outputs lam, slack, iters, status, best_resid; vA = best z' for the recovery of zhat
+template <class T> struct BigPhaseArgs {
+    int B, n, m, phase, it, maxIter, notImprovedLim, stall_policy;
+    T* fac; size_t fac_stride;
+    const T *p, *h; long long sp, sh;
+    T eps;
+    T *lam, *slack, *best_resid, *trace;
+    int *iters, *status;
+};
+
+template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const BigPhaseArgs<T>& a, int qp)
+{
+    const BigLayout L = big_layout(a.n, a.m);
+    T* F = a.fac + (size_t)qp * a.fac_stride;
+    T* sc = F + L.scal;
+    int* ctrl = reinterpret_cast<int*>(F + L.ctrl);
+    const int m = a.m, n = a.n, lane = b.lane();
+    const T mT = (T)m;
+    T *vP = F + L.v(bvP), *vC = F + L.v(bvC), *vR1 = F + L.v(bvR1), *vZ = F + L.v(bvZ), *vS = F + L.v(bvS);
+    T *vA = F + L.v(bvA), *vB = F + L.v(bvB), *vD = F + L.v(bvD), *vBZ = F + L.v(bvBZ), *vBS = F + L.v(bvBS);
+    T *vRH = F + L.v(bvRH), *vX = F + L.v(bvX), *vDZA = F + L.v(bvDZA), *vDSA = F + L.v(bvDSA), *vRSC = F + L.v(bvRSC);
+    T *vRZ = F + L.v(bvRZ), *vRS = F + L.v(bvRS), *vONE = F + L.v(bvONE);
+    if (a.phase == 6) {                          // end of the pre-factorisation: its failure bits are the status
+        if (lane == 0) a.status[qp] = ctrl[bcFail];
+        return;
+    }
+    if (a.phase == 0) {
+        const T* pg = a.p + (size_t)qp * a.sp;
+        const T* hg = a.h + (size_t)qp * a.sh;
+        for (int i = lane; i < L.VP; i += kWave) {
+            vP[i] = (i < n) ? pg[i] : T(0);
+            vC[i] = (i < m) ? hg[i] : T(0);
+            vD[i] = T(1);                        // 1 on the pad for every later factorisation
+            vONE[i] = (i < m) ? T(1) : T(0);
+            vZ[i] = vS[i] = vRZ[i] = vRS[i] = T(1);
+            vA[i] = vB[i] = vR1[i] = vBZ[i] = vBS[i] = vRH[i] = vX[i] = vDZA[i] = vDSA[i] = vRSC[i] = T(0);
+            (F + L.v(bvU))[i] = (F + L.v(bvW))[i] = (F + L.v(bvY))[i] = T(0);      // pads stay zero: the mat-vecs write the logical extent only
+        }
+        if (lane == 0) {
+            sc[bsTau] = T(1); sc[bsBtau] = T(1); sc[bsSigz] = T(0); sc[bsSigs] = T(0); sc[bsBres] = Lim<T>::inf();
+            sc[bsFeasPrev] = T(0); sc[bsAlphaPrev] = T(0); sc[bsMu] = T(0); sc[bsSzdot] = T(0);
+            ctrl[bcFail] &= (QPX_ST_Q_NOT_SPD | QPX_ST_A_RANK);       // a previous loop's breakdown does not count
+            ctrl[bcStop] = (ctrl[bcFail] != 0) ? 1 : 0;
+            ctrl[bcNnot] = 0; ctrl[bcFloor] = 0; ctrl[bcSt] = 0; ctrl[bcIters] = 0;
+        }
+        return;
+    }
+    if (a.phase == 5) {
+        const T bres = sc[bsBres];
+        int st = ctrl[bcSt];
+        const int iters = ctrl[bcIters];
+        const int fail = ctrl[bcFail];
+        if (fail & (QPX_ST_Q_NOT_SPD | QPX_ST_A_RANK)) {
+            const T nanv = Lim<T>::inf() - Lim<T>::inf();
+            for (int i = lane; i < m; i += kWave) { a.lam[(size_t)qp * m + i] = nanv; a.slack[(size_t)qp * m + i] = nanv; vA[i] = nanv; }
+            if (lane == 0) { a.iters[qp] = 0; a.best_resid[qp] = Lim<T>::inf(); a.status[qp] |= fail; }
+            return;
+        }
+        if (iters >= a.maxIter && !(bres < a.eps)) st |= QPX_ST_MAXITER;
+        if (!(bres <= T(1))) st |= QPX_ST_INACCURATE;
+        const T bts = sc[bsBtau] * sc[bsSigz];
+        for (int i = lane; i < L.VP; i += kWave) {
+            if (i < m) {
+                const T bz = vBZ[i];
+                a.lam[(size_t)qp * m + i] = bz;
+                a.slack[(size_t)qp * m + i] = vBS[i];
+                vA[i] = bz - bts;
+            } else {
+                vA[i] = T(0);
+            }
+        }
+        if (lane == 0) { a.iters[qp] = iters; a.status[qp] |= st | fail; a.best_resid[qp] = bres; }
+        return;
+    }
+    if (ctrl[bcStop]) return;
+    if (ctrl[bcFail]) {                          // a loop factorisation broke down: keep the best iterate
+        if (lane == 0) { ctrl[bcSt] |= QPX_ST_KKT_BREAKDOWN; ctrl[bcStop] = 1; }
+        if (a.phase == 1) for (int i = lane; i < m; i += kWave) { vBZ[i] = T(1); vBS[i] = T(1); }
+        return;
+    }
+    if (a.phase == 1) {
+        T x[NS];
+        ld_slots<NS>(b, x, vX, m, T(0));
+        T mnz = Lim<T>::inf(), mns = Lim<T>::inf();
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            if (i < m) { mnz = min2_(mnz, x[k]); mns = min2_(mns, -x[k]); }
+        }
+        mnz = wave_min(b, mnz);
+        mns = wave_min(b, mns);
+        const T sigz = (mnz < T(0)) ? (T(1) - mnz) : T(0);
+        const T sigs = (mns < T(0)) ? (T(1) - mns) : T(0);
+        if (lane == 0) { sc[bsSigz] = sigz; sc[bsSigs] = sigs; }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            if (i < m) {
+                const T zk = x[k] + sigz, sk = -x[k] + sigs;
+                vZ[i] = zk; vS[i] = sk; vA[i] = x[k]; vBZ[i] = zk; vBS[i] = sk;
+            }
+        }
+        return;
+    }
+    if (a.phase == 2) {
+        const int it = a.it;
+        const T tsz = sc[bsTau] * sc[bsSigz];
+        T pri2 = 0, szdot = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            if (i < m) {
+                const T zk = vZ[i], sk = vS[i];
+                const T rz = sk - vC[i] - vB[i];
+                pri2 = fma_(rz, rz, pri2);
+                szdot = fma_(sk, zk, szdot);
+                vRH[i] = vC[i] + vB[i] + tsz * vR1[i];
+                const T rzk = rcp_(zk);
+                vRZ[i] = rzk;
+                vRS[i] = rcp_(sk);
+                vD[i] = sk * rzk;
+            }
+        }
+        pri2 = wave_sum(b, pri2);
+        szdot = wave_sum(b, szdot);
+        const T mu = abs_(szdot / mT);
+        const T pri = sqrt_(pri2);
+        const T dual = tsz * sc[bsGt1];
+        const T feas = pri + dual, resid = feas + mT * mu;
+        const T tau = sc[bsTau];
+        T bres = sc[bsBres];
+        int nnot = ctrl[bcNnot], floor_hit = ctrl[bcFloor];
+        int stopf = 0;
+        const bool better = (it == 0) || (resid < bres);
+        if (better) {
+            bres = resid; nnot = 0;
+            for (int i = lane; i < m; i += kWave) { vBZ[i] = vZ[i]; vBS[i] = vS[i]; }
+        } else if (a.stall_policy == 1 || (a.stall_policy == 2 && mT * mu < feas)) {
+            nnot += 1;
+        } else {
+            nnot = 0;
+        }
+        if (a.stall_policy == 2 && it >= 1 && feas > T(2) * (T(1) - sc[bsAlphaPrev]) * sc[bsFeasPrev]) floor_hit = 1;
+        if ((a.stall_policy != 0 && nnot >= a.notImprovedLim) || bres < a.eps || mu > T(1e32)) stopf = 1;
+        if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-2) * feas) stopf = 1;
+        const bool bad = !finite_(resid);
+        if (bad) stopf = 1;
+        b.wave_sync();
+        if (lane == 0) {
+            sc[bsMu] = mu; sc[bsSzdot] = szdot;
+            ctrl[bcIters] = it + 1;
+            if (better) { sc[bsBres] = bres; sc[bsBtau] = tau; }
+            sc[bsFeasPrev] = feas;
+            ctrl[bcNnot] = nnot; ctrl[bcFloor] = floor_hit;
+            if (bad) ctrl[bcSt] |= QPX_ST_NONFINITE;
+            ctrl[bcStop] = stopf;
+            if (a.trace) {
+                T* tr = a.trace + ((size_t)it * a.B + qp) * 3;
+                tr[0] = pri; tr[1] = dual; tr[2] = mu;
+            }
+        }
+        return;
+    }
+    if (a.phase == 3) {
+        const T mu = sc[bsMu], szdot = sc[bsSzdot];
+        T z[NS], s[NS], rz[NS], rsv[NS], dd[NS], dza[NS], dsa[NS];
+        ld_slots<NS>(b, z, vZ, m, T(1));
+        ld_slots<NS>(b, s, vS, m, T(1));
+        ld_slots<NS>(b, rz, vRZ, m, T(1));
+        ld_slots<NS>(b, rsv, vRS, m, T(1));
+        ld_slots<NS>(b, dd, vD, m, T(1));
+        ld_slots<NS>(b, dza, vX, m, T(0));
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            dsa[k] = (i < m) ? (-s[k] - dza[k] * dd[k]) : T(0);
+        }
+        T al = step_to_boundary_rcp<NS>(b, rz, dza, m);
+        const T al2 = step_to_boundary_rcp<NS>(b, rsv, dsa, m);
+        al = min2_(al, al2);
+        al = min2_(al, T(1));
+        T t3 = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            if (i < m) t3 = fma_(s[k] + al * dsa[k], z[k] + al * dza[k], t3);
+        }
+        t3 = wave_sum(b, t3);
+        T sig = t3 / szdot;
+        sig = sig * sig * sig;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            if (i < m) {
+                const T rs = (-mu * sig + dsa[k] * dza[k]) * rsv[k];
+                vRSC[i] = rs;
+                vRH[i] = rs * dd[k];
+                vDZA[i] = dza[k];
+                vDSA[i] = dsa[k];
+            }
+        }
+        return;
+    }
+    if (a.phase == 4) {
+        T z[NS], s[NS], rz[NS], rsv[NS], dz[NS], ds[NS];
+        ld_slots<NS>(b, z, vZ, m, T(1));
+        ld_slots<NS>(b, s, vS, m, T(1));
+        ld_slots<NS>(b, rz, vRZ, m, T(1));
+        ld_slots<NS>(b, rsv, vRS, m, T(1));
+        ld_slots<NS>(b, dz, vX, m, T(0));
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            const T dsc = (i < m) ? ((-vRSC[i] - dz[k]) * vD[i]) : T(0);
+            dz[k] = (i < m) ? (vDZA[i] + dz[k]) : T(0);
+            ds[k] = (i < m) ? (vDSA[i] + dsc) : T(0);
+        }
+        T al = step_to_boundary_rcp<NS>(b, rz, dz, m);
+        const T al3 = step_to_boundary_rcp<NS>(b, rsv, ds, m);
+        al = min2_(al, al3);
+        al = T(0.999) * al;
+        al = min2_(al, T(1));
+        const T tau = (T(1) - al) * sc[bsTau];
+        const T tsz = tau * sc[bsSigz];
+        b.wave_sync();
+        if (lane == 0) { sc[bsTau] = tau; sc[bsAlphaPrev] = al; }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            if (i < m) {
+                const T zk = fma_(al, dz[k], z[k]);
+                vZ[i] = zk;
+                vS[i] = fma_(al, ds[k], s[k]);
+                vA[i] = zk - tsz;
+            }
+        }
+        return;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ small vector kernels
+// op 0: y = alpha x + beta y0 (elementwise, len);  op 1: y[0] = || x[0..len) ||_2 (one wave);
+// op 2: start of a pre-factorisation: zero the QP's control words, vONE = 1 on [0, m), 0 on the pad
+template <class T> struct BigVecArgs {
+    int B, op, len, n, m;
+    T* fac; size_t fac_stride;
+    const T *x, *y0; size_t sx, sy0;
+    T* y; size_t sy;
+    T alpha, beta;
+};
+template <class T> QPX_DEV void big_vec_body(const Block& b, const BigVecArgs<T>& a, int qp)
+{
+    if (a.op == 0) {
+        const T* x = a.x + (size_t)qp * a.sx;
+        const T* y0 = a.y0 ? a.y0 + (size_t)qp * a.sy0 : nullptr;
+        T* y = a.y + (size_t)qp * a.sy;
+        for (int i = b.tid; i < a.len; i += b.nt) y[i] = fma_(a.alpha, x[i], y0 ? a.beta * y0[i] : T(0));
+    } else if (a.op == 1) {
+        const T* x = a.x + (size_t)qp * a.sx;
+        if (b.wave() == 0) {
+            T acc = T(0);
+            for (int i = b.lane(); i < a.len; i += kWave) acc = fma_(x[i], x[i], acc);
+            acc = wave_sum(b, acc);
+            if (b.lane() == 0) (a.y + (size_t)qp * a.sy)[0] = sqrt_(acc);
+        }
+    } else {
+        const BigLayout L = big_layout(a.n, a.m);
+        T* F = a.fac + (size_t)qp * a.fac_stride;
+        int* ctrl = reinterpret_cast<int*>(F + L.ctrl);
+        if (b.tid < 16) ctrl[b.tid] = 0;
+        for (int i = b.tid; i < L.VP; i += b.nt) (F + L.v(bvONE))[i] = (i < a.m) ? T(1) : T(0);
+    }
+}
+
+// KKT solve / backward set-up and epilogue on the blob's vectors (one workgroup per QP)
+//   stage 0: vD = 1/d (d given, or clamp(lam)/clamp(slack) for backward), vRH <- rs/d - rz, vU <- rx (n, padded 0)
+//   stage 1: outputs: dz = vX, ds = (-rs - dz)/d, dx = vW; backward: dp, dh and the outer products
+template <class T> struct BigKktArgs {
+    int B, n, m, stage, backward;
+    T* fac; size_t fac_stride;
+    const T *d, *rx, *rs, *rz;
+    const T *zhat, *lam, *slack, *dl_dz;
+    T *dx, *ds, *dz, *dQ, *dp, *dG, *dh;
+    int* status;
+};
+template <class T> QPX_DEV void big_kkt_body(const Block& b, const BigKktArgs<T>& a, int qp, int chunk)
+{
+    const BigLayout L = big_layout(a.n, a.m);
+    T* F = a.fac + (size_t)qp * a.fac_stride;
+    int* ctrl = reinterpret_cast<int*>(F + L.ctrl);
+    const int n = a.n, m = a.m;
+    T *vD = F + L.v(bvD), *vRH = F + L.v(bvRH), *vU = F + L.v(bvU), *vX = F + L.v(bvX), *vW = F + L.v(bvW);
+    if (a.stage == 0) {
+        const T* rxg = a.backward ? a.dl_dz + (size_t)qp * n : (a.rx ? a.rx + (size_t)qp * n : nullptr);
+        for (int i = b.tid; i < L.VP; i += b.nt) {
+            T dinv = T(1), rhs = T(0);
+            if (i < m) {
+                T d;
+                if (a.backward) {
+                    const T l = a.lam[(size_t)qp * m + i], sl = a.slack[(size_t)qp * m + i];
+                    d = ((l < T(1e-8)) ? T(1e-8) : l) / ((sl < T(1e-8)) ? T(1e-8) : sl);       // qp.py:148
+                } else {
+                    d = a.d[(size_t)qp * m + i];
+                }
+                dinv = T(1) / d;
+                rhs = ((!a.backward && a.rs) ? a.rs[(size_t)qp * m + i] * dinv : T(0)) -
+                      ((!a.backward && a.rz) ? a.rz[(size_t)qp * m + i] : T(0));
+            }
+            vD[i] = dinv;
+            vRH[i] = rhs;
+            vU[i] = (i < n && rxg) ? rxg[i] : T(0);
+            vW[i] = T(0);
+        }
+        if (b.tid == 0) { ctrl[bcStop] = 0; ctrl[bcFail] &= (QPX_ST_Q_NOT_SPD | QPX_ST_A_RANK); }
+        return;
+    }
+    // stage 1, grid (B, 1 + rows of the outer products / 16)
+    if (chunk == 0) {
+        const bool bad = (ctrl[bcFail] & QPX_ST_KKT_BREAKDOWN) != 0;
+        if (b.tid == 0 && bad && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
+        for (int i = b.tid; i < n; i += b.nt) {
+            const T v = bad ? T(0) : vW[i];
+            if (a.backward) { if (a.dp) a.dp[(size_t)qp * n + i] = v; }
+            if (a.dx) a.dx[(size_t)qp * n + i] = v;
+        }
+        for (int i = b.tid; i < m; i += b.nt) {
+            const T dzv = bad ? T(0) : vX[i];
+            if (a.backward) { if (a.dh) a.dh[(size_t)qp * m + i] = -dzv; }
+            if (a.dz) a.dz[(size_t)qp * m + i] = dzv;
+            if (!a.backward && a.ds) a.ds[(size_t)qp * m + i] = (-(a.rs ? a.rs[(size_t)qp * m + i] : T(0)) - dzv) * vD[i];
+        }
+        return;
+    }
+    if (!a.backward) return;
+    const bool bad = (ctrl[bcFail] & QPX_ST_KKT_BREAKDOWN) != 0;
+    const T* zh = a.zhat + (size_t)qp * n;
+    const T* lm = a.lam + (size_t)qp * m;
+    const int r0 = (chunk - 1) * 16;
+    if (a.dQ)
+        for (int e = b.tid; e < 16 * n; e += b.nt) {
+            const int r = r0 + e / n, c = e % n;
+            if (r < n) a.dQ[((size_t)qp * n + r) * n + c] = bad ? T(0) : T(0.5) * (vW[r] * zh[c] + zh[r] * vW[c]);
+        }
+    if (a.dG)
+        for (int e = b.tid; e < 16 * n; e += b.nt) {
+            const int r = r0 + e / n, c = e % n;
+            if (r < m) a.dG[((size_t)qp * m + r) * n + c] = bad ? T(0) : (vX[r] * zh[c] + lm[r] * vW[c]);
+        }
+}
+
+}  // namespace qpx

@@ -270,50 +270,50 @@ QPX_LAYOUT_HD size_t lds_elems_ipm_grid(int gs, int nbl, int n, int q)
 
 // out[c] (op)= sum_r Mat[r][c] * vec[r]   -- thread per column c: the loads of a row are
 // coalesced across threads and independent across r (deep memory pipeline, no reduction).
-template <class T, int MODE /*0: =, 1: +=, 2: -=*/>
+template <class T, int MODE /*0: =, 1: +=, 2: -=*/, class Acc = T /* accumulate in (e.g. double for float data) */>
 QPX_DEV void block_matTvec(const Block& blk, T* out, const T* Mat, const T* vec, int rows, int cols)
 {
     for (int c = blk.tid; c < cols; c += blk.nt) {
         // eight independent loads in flight per thread: the rows come from L2 / HBM (~800 ticks each way)
-        T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+        Acc a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
         const T* col = Mat + c;
         int r = 0;
         for (; r + 8 <= rows; r += 8) {
             const T m0 = col[(size_t)r * cols], m1 = col[(size_t)(r + 1) * cols], m2 = col[(size_t)(r + 2) * cols];
             const T m3 = col[(size_t)(r + 3) * cols], m4 = col[(size_t)(r + 4) * cols], m5 = col[(size_t)(r + 5) * cols];
             const T m6 = col[(size_t)(r + 6) * cols], m7 = col[(size_t)(r + 7) * cols];
-            a0 = fma_(m0, vec[r], a0);
-            a1 = fma_(m1, vec[r + 1], a1);
-            a2 = fma_(m2, vec[r + 2], a2);
-            a3 = fma_(m3, vec[r + 3], a3);
-            a4 = fma_(m4, vec[r + 4], a4);
-            a5 = fma_(m5, vec[r + 5], a5);
-            a6 = fma_(m6, vec[r + 6], a6);
-            a7 = fma_(m7, vec[r + 7], a7);
+            a0 = fma_((Acc)m0, (Acc)vec[r], a0);
+            a1 = fma_((Acc)m1, (Acc)vec[r + 1], a1);
+            a2 = fma_((Acc)m2, (Acc)vec[r + 2], a2);
+            a3 = fma_((Acc)m3, (Acc)vec[r + 3], a3);
+            a4 = fma_((Acc)m4, (Acc)vec[r + 4], a4);
+            a5 = fma_((Acc)m5, (Acc)vec[r + 5], a5);
+            a6 = fma_((Acc)m6, (Acc)vec[r + 6], a6);
+            a7 = fma_((Acc)m7, (Acc)vec[r + 7], a7);
         }
-        for (; r < rows; ++r) a0 = fma_(col[(size_t)r * cols], vec[r], a0);
-        const T sum = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-        out[c] = MODE == 0 ? sum : (MODE == 1 ? out[c] + sum : out[c] - sum);
+        for (; r < rows; ++r) a0 = fma_((Acc)col[(size_t)r * cols], (Acc)vec[r], a0);
+        const Acc sum = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+        out[c] = MODE == 0 ? (T)sum : (MODE == 1 ? (T)((Acc)out[c] + sum) : (T)((Acc)out[c] - sum));
     }
 }
 
 // out[r] (op)= sum_c Mat[r][c] * vec[c]  -- row dots: a wave takes RB rows at a time, its lanes stride over the
 // columns (coalesced), RB independent loads in flight per lane, then RB wave reductions.
-template <class T, int MODE /*0: =, 1: +=, 2: -=*/>
+template <class T, int MODE /*0: =, 1: +=, 2: -=*/, class Acc = T>
 QPX_DEV void block_matvec(const Block& blk, T* out, const T* Mat, const T* vec, int rows, int cols)
 {
     constexpr int RB = 4;
     const int lane = blk.lane(), w = blk.uniform(blk.wave()), nw = blk.nwaves();
     for (int r0 = w * RB; r0 < rows; r0 += nw * RB) {
-        T acc[RB];
+        Acc acc[RB];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) acc[u] = T(0);
+        for (int u = 0; u < RB; ++u) acc[u] = Acc(0);
         for (int c = lane; c < cols; c += kWave) {
-            const T x = vec[c];
+            const Acc x = (Acc)vec[c];
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 const int r = (r0 + u < rows) ? r0 + u : rows - 1;      // clamped: loads stay unconditional
-                acc[u] = fma_(Mat[(size_t)r * cols + c], x, acc[u]);
+                acc[u] = fma_((Acc)Mat[(size_t)r * cols + c], x, acc[u]);
             }
         }
 #pragma unroll
@@ -321,7 +321,8 @@ QPX_DEV void block_matvec(const Block& blk, T* out, const T* Mat, const T* vec, 
         if (lane == 0) {
 #pragma unroll
             for (int u = 0; u < RB; ++u)
-                if (r0 + u < rows) out[r0 + u] = MODE == 0 ? acc[u] : (MODE == 1 ? out[r0 + u] + acc[u] : out[r0 + u] - acc[u]);
+                if (r0 + u < rows)
+                    out[r0 + u] = MODE == 0 ? (T)acc[u] : (MODE == 1 ? (T)((Acc)out[r0 + u] + acc[u]) : (T)((Acc)out[r0 + u] - acc[u]));
         }
     }
 }
@@ -924,7 +925,10 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
     T* vZH = vDY + v;     // zhat (n)   [backward]
     T* vLM = vZH + v;     // lam (m)    [backward]
     T* vNU = vLM + v;     // nu (q)     [backward]
-    T* scr = vNU + v;     // Mat::scratch_elems()
+    T* vCX = vNU + v;     // corrections of the iterative refinement (n, M8, q)
+    T* vCZ = vCX + v;
+    T* vCY = vCZ + v;
+    T* scr = vCY + v;     // Mat::scratch_elems()
 
     const T* rxg = kBackward ? (a.dl_dz + (size_t)qp * n) : (a.rx ? a.rx + (size_t)qp * n : nullptr);
     const T* rsg = (!kBackward && a.rs) ? a.rs + (size_t)qp * m : nullptr;
@@ -950,44 +954,83 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
         vRH[i] = rhs;
     }
     Mat::sync(b);
-    // rhs += M rx + W ry
-    block_matTvec<T, 1>(b, vRH, F + lay.MT, vRX, n, m);
-    if (q > 0) {
-        Mat::sync(b);
-        for (int j = b.tid; j < m; j += NT) {
-            T acc = vRH[j];
-            for (int r = 0; r < q; ++r) acc = fma_(F[lay.W + (size_t)j * q + r], vRY[r], acc);
-            vRH[j] = acc;
-        }
-    }
     typename Mat::Regs E;
     Mat::load(b, g, E, Mat::image(F, lay));
-    Mat::sync(b);
     Mat::add_diag(g, E, vD);
     const bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
     if (!ok && b.tid == 0 && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
-    if (ok) Mat::solve_neg(b, g, E, rd, m, vRH, vDZ, vTm, scr);
-    else {
-        for (int i = b.tid; i < M8; i += NT) vDZ[i] = T(0);
+
+    // One application of the condensed KKT inverse with the factor in E: inputs rX (n), rY (q) and rH = rs/d - rz (M8),
+    //   oZ = -T^-1 (rH + M rX + W rY),  oX = -K rX - M^T oZ - N rY,  oY = S11^-1 rY - N^T rX - W^T oZ   (rH is overwritten)
+    auto apply = [&](const T* rX, const T* rY, T* rH, T* oZ, T* oX, T* oY) {
+        block_matTvec<T, 1>(b, rH, F + lay.MT, rX, n, m);
+        if (q > 0) {
+            Mat::sync(b);
+            for (int j = b.tid; j < m; j += NT) {
+                T acc = rH[j];
+                for (int r = 0; r < q; ++r) acc = fma_(F[lay.W + (size_t)j * q + r], rY[r], acc);
+                rH[j] = acc;
+            }
+        }
         Mat::sync(b);
-    }
-    // dx = Kneg rx - M^T dz + NTn^T ry     (Kneg = -K, NTn = -N^T)
-    block_matTvec<T, 0>(b, vDX, F + lay.Kneg, vRX, n, n);
-    Mat::sync(b);
-    block_matvec<T, 2>(b, vDX, F + lay.MT, vDZ, n, m);
-    if (q > 0) {
+        if (ok) Mat::solve_neg(b, g, E, rd, m, rH, oZ, vTm, scr);
+        else {
+            for (int i = b.tid; i < M8; i += NT) oZ[i] = T(0);
+            Mat::sync(b);
+        }
+        // oX = Kneg rX - M^T oZ + NTn^T rY     (Kneg = -K, NTn = -N^T)
+        block_matTvec<T, 0>(b, oX, F + lay.Kneg, rX, n, n);
         Mat::sync(b);
-        block_matTvec<T, 1>(b, vDX, F + lay.NTn, vRY, q, n);
-        // dy = S11i ry + NTn rx - W^T dz
-        for (int r = b.tid; r < q; r += NT) {
-            T acc = 0;
-            for (int c2 = 0; c2 < q; ++c2) acc = fma_(F[lay.S11i + (size_t)r * q + c2], vRY[c2], acc);
-            for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], vRX[k], acc);
-            for (int j = 0; j < m; ++j) acc = fma_(-F[lay.W + (size_t)j * q + r], vDZ[j], acc);
-            vDY[r] = acc;
+        block_matvec<T, 2>(b, oX, F + lay.MT, oZ, n, m);
+        if (q > 0) {
+            Mat::sync(b);
+            block_matTvec<T, 1>(b, oX, F + lay.NTn, rY, q, n);
+            for (int r = b.tid; r < q; r += NT) {
+                T acc = 0;
+                for (int c2 = 0; c2 < q; ++c2) acc = fma_(F[lay.S11i + (size_t)r * q + c2], rY[c2], acc);
+                for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], rX[k], acc);
+                for (int j = 0; j < m; ++j) acc = fma_(-F[lay.W + (size_t)j * q + r], oZ[j], acc);
+                oY[r] = acc;
+            }
+        }
+        Mat::sync(b);
+    };
+    apply(vRX, vRY, vRH, vDZ, vDX, vDY);
+
+    // Iterative refinement on the residual of the ORIGINAL KKT system (batch.py:244-270, solve_kkt_ir; the factor
+    // is re-used, not re-computed as there):  res = K sol + rhs  with the caller's Q, G, A,  sol += K~^-1 (-res).
+    //   resx = Q dx + G^T dz + A^T dy + rx,   resz = G dx + ds + rz  (ds = (-rs - dz)/d, so ress = 0),   resy = A dx + ry
+    if (a.refine > 0 && a.Q && a.G) {
+        const T* Qg = a.Q + (size_t)qp * a.sQ;
+        const T* Gg = a.G + (size_t)qp * a.sG;
+        const T* Ag = (q > 0 && a.A) ? a.A + (size_t)qp * a.sA : nullptr;
+        for (int it = 0; it < a.refine; ++it) {
+            for (int i = b.tid; i < n; i += NT) vRX[i] = rxg ? rxg[i] : T(0);
+            for (int i = b.tid; i < q; i += NT) vRY[i] = ryg ? ryg[i] : T(0);
+            for (int i = b.tid; i < M8; i += NT)     // -(ds + rz): the part of -resz that needs no matrix
+                vRH[i] = (i < m) ? -((-(rsg ? rsg[i] : T(0)) - vDZ[i]) * vD[i] + (rzg ? rzg[i] : T(0))) : T(0);
+            Mat::sync(b);
+            // residuals accumulate in double whatever T is: fixed-precision refinement cannot improve the forward
+            // error of an ill-conditioned solve (cond(Q) ~ 1e6 on the benchmark generator), mixed precision can
+            block_matTvec<T, 1, double>(b, vRX, Qg, vDX, n, n);           // Q symmetric: column-parallel over its rows
+            Mat::sync(b);
+            block_matTvec<T, 1, double>(b, vRX, Gg, vDZ, m, n);           // + G^T dz
+            block_matvec<T, 2, double>(b, vRH, Gg, vDX, m, n);            // - G dx
+            if (Ag) {
+                Mat::sync(b);
+                block_matTvec<T, 1, double>(b, vRX, Ag, vDY, q, n);       // + A^T dy
+                block_matvec<T, 1, double>(b, vRY, Ag, vDX, q, n);        // + A dx
+            }
+            Mat::sync(b);
+            // correction = K~^-1 (-res):  apply() solves K c = -(rX, ., rH-part, rY) for right-hand sides given as
+            // (rx, rs/d - rz, ry), so pass resx, -resz (rs = 0), resy
+            apply(vRX, vRY, vRH, vCZ, vCX, vCY);
+            for (int i = b.tid; i < n; i += NT) vDX[i] += vCX[i];
+            for (int i = b.tid; i < M8; i += NT) vDZ[i] += vCZ[i];
+            for (int i = b.tid; i < q; i += NT) vDY[i] += vCY[i];
+            Mat::sync(b);
         }
     }
-    Mat::sync(b);
     if (!kBackward) {
         for (int i = b.tid; i < n; i += NT) a.dx[(size_t)qp * n + i] = vDX[i];
         for (int i = b.tid; i < m; i += NT) {
@@ -1049,7 +1092,7 @@ QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
 QPX_LAYOUT_HD size_t lds_elems_kkt_mat(size_t mp, size_t scratch, int n, int q)
 {
     const size_t v = align4(max2(max2((size_t)n, mp), (size_t)q));
-    return 12 * v + scratch;
+    return 15 * v + scratch;
 }
 QPX_LAYOUT_HD size_t lds_elems_kkt_grid(int gs, int nbl, int n, int q)
 {

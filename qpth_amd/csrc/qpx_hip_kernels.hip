@@ -7,7 +7,7 @@
 // Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm (workgroup per QP),
 // 3 = kkt/backward, 5 = sweep pre-factorisation (16x16 thread grid),
 // 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only),
-// 10 = batch-mean outer products of shared-parameter gradients.
+// 10 = batch-mean outer products of shared-parameter gradients, 11 = the large-QP family (qpx_big.h).
 #include <hip/hip_runtime.h>
 
 #include "../../include/qpx.h"
@@ -161,7 +161,7 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
 }
 #define QPX_INSTG(NBL, NS) template int launch_ipm_grid8<QPX_TU_REAL, NBL, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) QPX_INSTG(8, 2) QPX_INSTG(13, 2)
-#elif QPX_TU_KERNEL == 10
+#elif QPX_TU_KERNEL == 10 || QPX_TU_KERNEL == 11
 // defined below, outside the launcher chain
 #elif QPX_TU_KERNEL == 9
 // NW waves per QP, always at least two waves per SIMD (<= 256 registers per lane): at that occupancy the
@@ -223,6 +223,63 @@ QPX_INSTT(1, 1, 1) QPX_INSTT(1, 1, 2) QPX_INSTT(1, 1, 4) QPX_INSTT(2, 1, 1) QPX_
 QPX_INSTT(4, 1, 1) QPX_INSTT(4, 1, 2) QPX_INSTT(4, 1, 4) QPX_INSTT(4, 2, 1) QPX_INSTT(4, 2, 2) QPX_INSTT(4, 2, 4)
 QPX_INSTT(7, 2, 2) QPX_INSTT(7, 2, 4) QPX_INSTT(7, 4, 2) QPX_INSTT(7, 4, 4)
 #endif
+#endif
+
+#if QPX_TU_KERNEL == 11
+// ---- the large-QP family (qpx_big.h): grid (B, chunks), 256 threads (phase kernel: one wave)
+#define QPX_BIG_KERNEL(NAME, ARGS, BODY, THREADS)                                                        \
+    template <class T> __global__ __launch_bounds__(THREADS) void NAME(ARGS<T> a)                        \
+    {                                                                                                    \
+        extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];                         \
+        const Block b{(int)threadIdx.x, (int)blockDim.x};                                                \
+        BODY;                                                                                            \
+    }
+QPX_BIG_KERNEL(k_big_pack, BigPackArgs, (big_pack_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y)), 256)
+QPX_BIG_KERNEL(k_big_panel, BigPanelArgs, (big_panel_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem))), 256)
+QPX_BIG_KERNEL(k_big_gemm, BigGemmArgs, (big_gemm_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
+QPX_BIG_KERNEL(k_big_trsv, BigTrsvArgs, (big_trsv_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem))), 256)
+QPX_BIG_KERNEL(k_big_gemv, BigGemvArgs, (big_gemv_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
+QPX_BIG_KERNEL(k_big_vec, BigVecArgs, (big_vec_body<T>(b, a, (int)blockIdx.x)), 256)
+QPX_BIG_KERNEL(k_big_kkt, BigKktArgs, (big_kkt_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y)), 256)
+template <class T, int NS> __global__ __launch_bounds__(64) void k_big_phase(BigPhaseArgs<T> a)
+{
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    big_phase_body<T, NS>(b, a, (int)blockIdx.x);
+}
+template <class K, class A> static int big_launch(K kern, const A& a, int gx, int gy, int threads, size_t lds, void* stream, bool& big_ok)
+{
+    if (allow_big_lds(kern, lds, big_ok)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(threads), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void* s) { static bool f = false; return big_launch(k_big_pack<T>, a, a.B, gy, 256, 0, s, f); }
+template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void* s) { static bool f = false; return big_launch(k_big_panel<T>, a, a.B, 1, 256, big_panel_lds_elems() * sizeof(T), s, f); }
+template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* s) { static bool f = false; return big_launch(k_big_gemm<T>, a, a.B, a.nti * a.ntj, 256, big_gemm_lds_elems() * sizeof(T), s, f); }
+template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* s) { static bool f = false; return big_launch(k_big_trsv<T>, a, a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f); }
+template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* s)
+{
+    static bool f = false;
+    const int outs = a.trans ? a.cols : a.rows;
+    return big_launch(k_big_gemv<T>, a, a.B, (outs + kBB - 1) / kBB, 256, 4 * kWave * sizeof(T), s, f);
+}
+template <class T> int launch_big_vec(const BigVecArgs<T>& a, void* s) { static bool f = false; return big_launch(k_big_vec<T>, a, a.B, 1, 256, 0, s, f); }
+template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* s) { static bool f = false; return big_launch(k_big_kkt<T>, a, a.B, gy, 256, 0, s, f); }
+template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* s)
+{
+    static bool f = false;
+    const int ns = big_pad(a.m) / kWave;
+    switch (ns) {
+    case 1: return big_launch(k_big_phase<T, 1>, a, a.B, 1, 64, 0, s, f);
+    case 2: return big_launch(k_big_phase<T, 2>, a, a.B, 1, 64, 0, s, f);
+    case 3: case 4: return big_launch(k_big_phase<T, 4>, a, a.B, 1, 64, 0, s, f);
+    default: return big_launch(k_big_phase<T, 8>, a, a.B, 1, 64, 0, s, f);
+    }
+}
+#define QPX_INSTB(NAME, ARGS) template int NAME<QPX_TU_REAL>(const ARGS<QPX_TU_REAL>&, void*);
+template int launch_big_pack<QPX_TU_REAL>(const BigPackArgs<QPX_TU_REAL>&, int, void*);
+template int launch_big_kkt<QPX_TU_REAL>(const BigKktArgs<QPX_TU_REAL>&, int, void*);
+QPX_INSTB(launch_big_panel, BigPanelArgs) QPX_INSTB(launch_big_gemm, BigGemmArgs) QPX_INSTB(launch_big_trsv, BigTrsvArgs) QPX_INSTB(launch_big_gemv, BigGemvArgs)
+QPX_INSTB(launch_big_vec, BigVecArgs) QPX_INSTB(launch_big_phase, BigPhaseArgs)
 #endif
 
 #if QPX_TU_KERNEL == 10

@@ -317,6 +317,11 @@ template <class T> struct KktArgs {
     T *dQ, *dp, *dG, *dh, *dA, *db;       // backward: any of them may be NULL (gradient not wanted)
     int* status;
     int images;                           // blob family the factors were written in (fac_layout)
+    // iterative refinement on the residual of the original KKT system (batch.py:244-270): steps, and the caller's
+    // Q (B,n,n), G (B,m,n), A (B,q,n) with their batch strides; refine = 0 or Q = NULL: none
+    int refine;
+    const T *Q, *G, *A;
+    long long sQ, sG, sA;
 };
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB of LDS per workgroup

@@ -9,6 +9,7 @@
 #include "qpx_grid.h"
 #include "qpx_tile.h"
 #include "qpx_reduce.h"
+#include "qpx_big.h"
 
 namespace qpx {
 
@@ -36,5 +37,15 @@ template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, s
 
 // batch-mean outer products of shared-parameter gradients (qpx_reduce.h): grid (tiles, batch chunks), one wave each
 template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int chunks, void* stream);
+
+// the large-QP family (qpx_big.h): every launch covers the batch; gy = workgroups per QP
+template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void* stream);
+template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void* stream);
+template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* stream);
+template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* stream);
+template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* stream);
+template <class T> int launch_big_vec(const BigVecArgs<T>& a, void* stream);
+template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* stream);
+template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* stream);
 
 }  // namespace qpx

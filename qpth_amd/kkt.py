@@ -76,6 +76,7 @@ class KKTFactors:
                 tuple(Q.shape), tuple(G.shape), tuple(A.shape) if A is not None else ()))
         self.lib = _lib.backend_for(Q)
         self.dtype, self.device = Q.dtype, Q.device
+        self.Q, self.G, self.A = Q, G, (A if self.q else None)     # the original data: iterative refinement evaluates residuals with it
         code = _lib.QPX_F64 if Q.dtype == torch.float64 else _lib.QPX_F32
         self.elems = self.lib.factor_elems(code, self.n, self.m, self.q)
         # the A/B knob of the library is per host thread and selects the blob layout: remember the value the
@@ -166,7 +167,9 @@ a non-zero diagonal.
         return r
 
     # -- factor_kkt + solve_kkt (batch.py:435-470, 349-372) ----------------------------------
-    def solve_kkt(self, d, rx, rs, rz, ry):
+    def solve_kkt(self, d, rx, rs, rz, ry, refine=0):
+        """factor_kkt + solve_kkt; refine > 0: that many steps of iterative refinement on the residual of the original
+        KKT system (batch.py:228-270, KKTSolvers.IR_UNOPT) inside the kernel, re-using the factorisation."""
         B, n, m, q = self.B, self.n, self.m, self.q
         dt, dev = self.dtype, self.device
         d = self._vec(d, m)
@@ -176,11 +179,66 @@ a non-zero diagonal.
         dy = torch.empty(B, q, dtype=dt, device=dev) if q else None
         with self._knob():
             self.lib.factor_solve_kkt(B, n, m, q, self.blob, self.sfac, d, self._vec(rx, n), self._vec(rs, m),
-                                      self._vec(rz, m), self._vec(ry, q), dx, ds, dz, dy, self.status)
+                                      self._vec(rz, m), self._vec(ry, q), dx, ds, dz, dy, self.status,
+                                      refine=refine, Q=self.Q, G=self.G, A=self.A)
         return dx, ds, dz, dy
 
+    # -- KKTSolvers.IR_UNOPT (batch.py:244-270) as a finishing stage --------------------------------
+    def polish(self, p, h, b, res, steps=3, refine=1):
+        """`steps` iterations of the reference's PDIPM loop (batch.py:92-198: affine + centring-corrector) in the ORIGINAL
+        variables (x, s, z, y), started from the loop kernel's result, with the KKT residuals evaluated from the
+        caller's Q, G, A in float64 and every solve refined in the kernel (solve_kkt(..., refine)).  The loop kernel iterates on pre-computed products (R = G Q^-1 G^T, ...): in float32
+        their rounding error (cond(Q) ~ 1e6 on the benchmark generator) is a perturbation of the PROBLEM that no
+        number of loop iterations removes; residuals against the original data do.  No host sync."""
+        B, n, m, q = self.B, self.n, self.m, self.q
+        hp = torch.float64
+        ex = lambda X, nd: (X if X.dim() == nd else X.unsqueeze(0).expand(B, *X.shape)).to(hp)   # noqa: E731
+        Q, G = ex(self.Q, 3), ex(self.G, 3)
+        pp, hh = ex(p, 2), ex(h, 2)
+        A = ex(self.A, 3) if q else None
+        bb = ex(b, 2) if q else None
+        x, z, s = res.zhat.to(hp), res.lam.to(hp), res.slacks.to(hp)
+        y = res.nu.to(hp) if q else None
+        tiny = torch.finfo(self.dtype).tiny
+        dt = self.dtype
+
+        def step(v, dv):
+            r = torch.where(dv < 0, -v / dv.clamp_max(-tiny), torch.full_like(v, float("inf")))
+            return r.min(1, keepdim=True)[0]
+
+        def solve(d, rx, rs, rz, ry):
+            o = self.solve_kkt(d.to(dt), rx.to(dt), rs.to(dt), rz.to(dt), ry.to(dt) if q else None, refine=refine)
+            return [v.to(hp) if v is not None else None for v in o]
+
+        for _ in range(steps):
+            # one iteration of the reference's loop (batch.py:92-198) in float64 vector arithmetic
+            rx = torch.einsum("bij,bj->bi", Q, x) + pp + torch.einsum("bmi,bm->bi", G, z)
+            rz = torch.einsum("bmi,bi->bm", G, x) + s - hh
+            ry = None
+            if q:
+                rx = rx + torch.einsum("bqi,bq->bi", A, y)
+                ry = torch.einsum("bqi,bi->bq", A, x) - bb
+            sc, zc = s.clamp_min(tiny), z.clamp_min(tiny)
+            d = zc / sc
+            mu = (s * z).sum(1, keepdim=True).abs() / m
+            dxa, dsa, dza, dya = solve(d, rx, z, rz, ry)                                        # affine direction
+            al = torch.minimum(step(z, dza), step(s, dsa)).clamp_max(1.0)
+            sig = (((s + al * dsa) * (z + al * dza)).sum(1, keepdim=True) / (s * z).sum(1, keepdim=True)) ** 3
+            rsc = (-mu * sig + dsa * dza) / sc
+            zero_n, zero_m = torch.zeros_like(rx), torch.zeros_like(rz)
+            dxc, dsc, dzc, dyc = solve(d, zero_n, rsc, zero_m, torch.zeros_like(ry) if q else None)   # corrector
+            dx, ds, dz = dxa + dxc, dsa + dsc, dza + dzc
+            alpha = (0.999 * torch.minimum(step(z, dz), step(s, ds))).clamp_max(1.0)
+            x, s, z = x + alpha * dx, s + alpha * ds, z + alpha * dz
+            if q:
+                y = y + alpha * (dya + dyc)
+        res.zhat, res.lam, res.slacks = x.to(self.dtype), z.to(self.dtype), s.to(self.dtype)
+        if q:
+            res.nu = y.to(self.dtype)
+        return res
+
     # -- QPFunctionFn.backward (qp.py:127-182) ------------------------------------------------
-    def backward(self, zhat, lam, slacks, nu, dl_dz, want=(True,) * 6, shared=(False,) * 6):
+    def backward(self, zhat, lam, slacks, nu, dl_dz, want=(True,) * 6, shared=(False,) * 6, refine=0):
         """Gradients (dQ, dp, dG, dh, dA, db) for the parameters `want` asks for (ctx.needs_input_grad;
         the others come back as None and cost nothing).  A parameter flagged in `shared` is one the whole
         batch shares: its gradient is returned already reduced to the reference's `.mean(0)` (qp.py:159-177)
@@ -205,7 +263,8 @@ a non-zero diagonal.
         zh, lm, nv = self._vec(zhat, n), self._vec(lam, m), self._vec(nu, q)
         with self._knob():
             self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m), nv,
-                              self._vec(dl_dz, n), dQ, None, dG, None, dA, None, self.status, dx, dz, dy)
+                              self._vec(dl_dz, n), dQ, None, dG, None, dA, None, self.status, dx, dz, dy,
+                              refine=refine, Q=self.Q, G=self.G, A=self.A)
         if wQ and sQ:
             dQ = torch.empty(n, n, dtype=dt, device=dev)
             self.lib.batch_outer(dx, zh, zh, dx, 0.5, dQ)

@@ -36,7 +36,13 @@ def _print_trace(res):
 
 def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                maxIter=20, solver=QPSolvers.PDIPM_BATCHED,
-               check_Q_spd=True):
+               check_Q_spd=True, refine=None):
+    """`refine` is the one argument the reference does not have: the number of finishing Newton steps on the residuals
+    of the ORIGINAL problem data (KKTFactors.polish -- the reference's KKTSolvers.IR_UNOPT idea, batch.py:244-270)
+    (each with one in-kernel refinement step per KKT solve, also applied to the backward solve).  None = automatic:
+    3 in float32 (whose pre-computed products R = G Q^-1 G^T carry ~1e-2 relative error on the benchmark generator:
+    the loop kernel alone lands 20x further from the float64 answer than the reference's float32 run does), 0 in
+    float64.  refine=0 is the fast float32 path."""
     class QPFunctionFn(Function):
         @staticmethod
         def forward(ctx, Q_, p_, G_, h_, A_, b_):
@@ -57,6 +63,9 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                 fac = KKTFactors.build(Q, G, A, nBatch)            # qp.py:93
                 res = fac.ipm(p, h, b, eps, maxIter, notImprovedLim,
                               want_trace=(verbose == 1))             # qp.py:94-96
+                ctx.refine = (3 if Q.dtype == torch.float32 else 0) if refine is None else int(refine)
+                if ctx.refine > 0:
+                    res = fac.polish(p, h, b, res, steps=ctx.refine, refine=1)
                 # one small read-back: the reference raises here too (qp.py:81-85, batch.py:379-386)
                 fac.raise_on_failure(check_Q_spd)
                 if verbose == 1:
@@ -71,6 +80,7 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                 from .solvers import external
                 zhats, ctx.nus, ctx.lams, ctx.slacks = external.forward_batch(Q, p, G, h, A, b, neq)
                 ctx.fac = None
+                ctx.refine = 0 if refine is None else int(refine)
             else:
                 assert False
 
@@ -101,7 +111,7 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
             # the batch instead of nBatch outer products.
             want = tuple(ctx.needs_input_grad[:6])
             grads = fac.backward(zhats, ctx.lams, ctx.slacks, ctx.nus, dl_dzhat, want=want,
-                                 shared=(Q_e, p_e, G_e, h_e, A_e, b_e))
+                                 shared=(Q_e, p_e, G_e, h_e, A_e, b_e), refine=1 if ctx.refine > 0 else 0)
             if neq == 0:
                 grads = grads[:4] + (None, None)
             return grads

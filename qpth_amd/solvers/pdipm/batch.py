@@ -83,18 +83,28 @@ def solve_kkt(Q_LU, d, G, A, S_LU, rx, rs, rz, ry):
     return fac.solve_kkt(d, rx, rs, rz, ry)
 
 
+def solve_kkt_ir(Q_LU, d, G, A, S_LU, rx, rs, rz, ry, niter=1):
+    """The reference's solve_kkt_ir (batch.py:244-270) on the pre-factored handles: solve, then `niter` steps of
+    iterative refinement on the residual of the original KKT system (kkt_resid_reg, batch.py:228-241) -- inside the
+    kernel, with the factorisation re-used.  (No eps-regularisation: the un-pivoted factorisations here need none.)"""
+    return Q_LU.fac.solve_kkt(d, rx, rs, rz, ry, refine=niter)
+
+
 def forward(Q, p, G, h, A, b, Q_LU, S_LU, R, eps=1e-12, verbose=0, notImprovedLim=3,
             maxIter=20, solver=KKTSolvers.LU_PARTIAL, stall_policy=None):
     """
     Q_LU, S_LU, R = pre_factor_kkt(Q, G, A)
     """
-    if solver != KKTSolvers.LU_PARTIAL:
-        raise NotImplementedError(
-            "qpth_amd implements the KKT solver QPFunction uses (LU_PARTIAL, qp.py:94-96); "
-            "%s is reachable in the reference only by calling forward() directly." % solver)
+    if not isinstance(solver, KKTSolvers):
+        raise ValueError("solver must be a KKTSolvers member, got %r" % (solver,))
     nineq, nz, neq, nBatch = get_sizes(G, A)
     fac = Q_LU.fac
+    # LU_FULL and LU_PARTIAL are two elimination orders of one KKT system in the reference (batch.py:313-346 vs
+    # 349-372, same iterates to rounding: test.py:222-234); the HIP path has one elimination, the condensed one,
+    # and runs it for both.  IR_UNOPT adds what its name promises: steps on the residual of the ORIGINAL system.
     res = fac.ipm(p, h, b, eps, maxIter, notImprovedLim, stall_policy, want_trace=(verbose == 1))
+    if solver == KKTSolvers.IR_UNOPT:
+        res = fac.polish(p, h, b, res)
     if verbose == 1:
         tr = res.trace.cpu()
         it_max = int(res.iters.max().item())

@@ -5,7 +5,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-EMU_SO = os.path.join(HERE, "_build", "libqpx_emu.so")
+EMU_SO = os.environ.get("QPX_EMU_SO") or os.path.join(HERE, "_build", "libqpx_emu.so")
 
 
 def build():

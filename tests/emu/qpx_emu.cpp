@@ -16,6 +16,7 @@
 #include "qpx_grid.h"
 #include "qpx_tile.h"
 #include "qpx_reduce.h"
+#include "qpx_big.h"
 
 // Extra bytes behind the emulated LDS block.  The sanitizer build uses 0 so that an index one element past
 // the size the launcher computed is already a reported overflow.
@@ -173,6 +174,64 @@ template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, s
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(256, [&](const Block& b) { kkt_grid_body<T, 16, NBL, kBw>(b, a, qp, base); });
     }
+    return QPX_OK;
+}
+
+// the large-QP family: grid (B, gy) of workgroups, one after the other
+template <class F> static void big_grid(int B, int gy, int threads, size_t lds_bytes, const F& body)
+{
+    for (int y = 0; y < gy; ++y)
+        for (int qp = 0; qp < B; ++qp) {
+            std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
+            unsigned char* base = lds.data();
+            run_block(threads, [&](const Block& b) { body(b, qp, y, base); });
+        }
+}
+template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void*)
+{
+    big_grid(a.B, gy, 256, 0, [&](const Block& b, int qp, int y, unsigned char*) { big_pack_body<T>(b, a, qp, y); });
+    return QPX_OK;
+}
+template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void*)
+{
+    big_grid(a.B, 1, 256, big_panel_lds_elems() * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_panel_body<T>(b, a, qp, reinterpret_cast<T*>(l)); });
+    return QPX_OK;
+}
+template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void*)
+{
+    big_grid(a.B, a.nti * a.ntj, 256, big_gemm_lds_elems() * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemm_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
+    return QPX_OK;
+}
+template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void*)
+{
+    big_grid(a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_trsv_body<T>(b, a, qp, reinterpret_cast<T*>(l)); });
+    return QPX_OK;
+}
+template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void*)
+{
+    const int outs = a.trans ? a.cols : a.rows;
+    big_grid(a.B, (outs + kBB - 1) / kBB, 256, 4 * kWave * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemv_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
+    return QPX_OK;
+}
+template <class T> int launch_big_vec(const BigVecArgs<T>& a, void*)
+{
+    big_grid(a.B, 1, 256, 0, [&](const Block& b, int qp, int, unsigned char*) { big_vec_body<T>(b, a, qp); });
+    return QPX_OK;
+}
+template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void*)
+{
+    big_grid(a.B, gy, 256, 0, [&](const Block& b, int qp, int y, unsigned char*) { big_kkt_body<T>(b, a, qp, y); });
+    return QPX_OK;
+}
+template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void*)
+{
+    const int ns = big_pad(a.m) / kWave;
+    big_grid(a.B, 1, 64, 0, [&](const Block& b, int qp, int, unsigned char*) {
+        if (ns == 1) big_phase_body<T, 1>(b, a, qp);
+        else if (ns == 2) big_phase_body<T, 2>(b, a, qp);
+        else if (ns <= 4) big_phase_body<T, 4>(b, a, qp);
+        else big_phase_body<T, 8>(b, a, qp);
+    });
     return QPX_OK;
 }
 

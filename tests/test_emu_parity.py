@@ -279,6 +279,26 @@ def test_edge_shapes_match_the_reference(name):
             assert np.abs(gr - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
 
 
+# ---------------------------------------------------------------- round 2: the large-QP family (qpx_big.h)
+@pytest.mark.parametrize("shape,dtype", [((1, 66, 70), torch.float64), ((1, 20, 70), torch.float32)])
+def test_large_qp_family(shape, dtype):
+    """BASELINE.json configs[3] runs through a multi-kernel family (blocked Cholesky / triangular solves / MFMA trailing
+    updates on 64 x 64 blocks, matrices in HBM).  Forced here (knob 3) at sizes of two and three blocks so that the
+    blocked code paths run on the emulator: zhat and every gradient against the oracle."""
+    B, n, m = shape
+    f32 = dtype == torch.float32
+    arrs = problems.prof_qp(B, n, m, 0, seed=3, dtype=np.float32 if f32 else np.float64)
+    arrs64 = problems.prof_qp(B, n, m, 0, seed=3)
+    dl = np.random.RandomState(0).randn(B, n)
+    x, y, lam, s, grads, info = orc.qp_forward_backward(*arrs64, dl_dz=dl, per_qp=True, stall_policy=2)
+    z, mine = run_qpf(arrs, dl.astype(arrs[0].dtype), dtype=dtype, threads=256, variant=3)
+    tol = 5e-3 if f32 else TOL
+    assert rel_err(z, x).max() < tol
+    for a_, r_ in zip(mine, grads):
+        if r_ is not None:
+            assert np.abs(a_ - r_).max() <= 20 * tol * max(1.0, np.abs(r_).max())
+
+
 # ---------------------------------------------------------------- round 2: host logic around the new C-ABI arguments
 @pytest.mark.parametrize("name", ["c3s_b4_n20_m10_q4_f64", "broadcast_b5_n12_m9_q3"])
 def test_backward_from_external_solutions(name):
@@ -352,3 +372,73 @@ def test_shared_parameter_gradients_are_one_contraction(dtype):
     with emulated():
         fac = KKTFactors.build(tq[0], tq[2], tq[4], nBatch=5)
     assert fac.shared and fac.blob.numel() == fac.elems
+
+
+# ---------------------------------------------------------------- round 2: accuracy options (batch.py:216-346)
+def _kkt_residual(Q, G, A, d, rx, rs, rz, ry, dx, ds, dz, dy):
+    """|| K sol + rhs || of the reference's KKT system (kkt_resid_reg, batch.py:228-241), in float64"""
+    f = lambda v: np.asarray(v, np.float64)
+    Q, G, A, d, rx, rs, rz, ry, dx, ds, dz, dy = [f(v) for v in (Q, G, A, d, rx, rs, rz, ry, dx, ds, dz, dy)]
+    e1 = np.einsum('bij,bj->bi', Q, dx) + np.einsum('bmi,bm->bi', G, dz) + np.einsum('bqi,bq->bi', A, dy) + rx
+    e2 = d * ds + dz + rs
+    e3 = np.einsum('bmi,bi->bm', G, dx) + ds + rz
+    e4 = np.einsum('bqi,bi->bq', A, dx) + ry
+    return np.sqrt((e1 ** 2).sum(1) + (e2 ** 2).sum(1) + (e3 ** 2).sum(1) + (e4 ** 2).sum(1))
+
+
+def test_iterative_refinement_of_the_kkt_solve():
+    """solve_kkt_ir (batch.py:244-270): refinement on the residual of the ORIGINAL system inside the kernel (residuals
+    accumulated in float64).  In float32 on the benchmark generator one step cuts the KKT residual by > 50x; in
+    float64 the refined solve still equals the reference's (test.py:236-247, test_ir_kkt_solver)."""
+    B, n, m, q = 3, 30, 20, 4
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed=2, dtype=np.float32)
+    r = np.random.RandomState(1)
+    d = (r.rand(B, m) + 0.1).astype(np.float32)
+    rx, rs, rz, ry = [r.randn(B, k).astype(np.float32) for k in (n, m, m, q)]
+    tt = lambda x: torch.tensor(x)   # noqa: E731
+    with emulated():
+        Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(tt(Q), tt(G), tt(A))
+        o0 = pdipm_b.solve_kkt(Q_LU, tt(d), tt(G), tt(A), S_LU, tt(rx), tt(rs), tt(rz), tt(ry))
+        o1 = pdipm_b.solve_kkt_ir(Q_LU, tt(d), tt(G), tt(A), S_LU, tt(rx), tt(rs), tt(rz), tt(ry), niter=1)
+    r0 = _kkt_residual(Q, G, A, d, rx, rs, rz, ry, *[v.numpy() for v in o0])
+    r1 = _kkt_residual(Q, G, A, d, rx, rs, rz, ry, *[v.numpy() for v in o1])
+    assert (r1 < r0 / 50).all(), (r0, r1)
+    g = load_golden("kkt_solver")
+    Qg, pg, Gg, hg, Ag, bg = tens([g[k] for k in ("Q", "p", "G", "h", "A", "b")], grad=False)
+    Qe, Ae = Qg.unsqueeze(0).expand(2, 5, 5), Ag.unsqueeze(0).expand(2, 3, 5)
+    dd, rxx, rss, rzz, ryy = tens([g[k] for k in ("d", "rx", "rs", "rz", "ry")], grad=False)
+    with emulated():
+        Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(Qe, Gg, Ae)
+        outs = pdipm_b.solve_kkt_ir(Q_LU, dd, Gg, Ae, S_LU, rxx, rss, rzz, ryy, niter=1)
+    for mine, key in zip(outs, ("dx", "ds", "dz", "dy")):
+        assert np.allclose(mine.numpy(), g["full_" + key], rtol=1e-4, atol=1e-2), key     # test.py:243-246
+        assert np.allclose(mine.numpy(), g[key], rtol=1e-8, atol=1e-9), key
+
+
+@pytest.mark.parametrize("solver", ["LU_FULL", "LU_PARTIAL", "IR_UNOPT"])
+def test_forward_accepts_every_kkt_solver(solver):
+    """forward(..., solver=KKTSolvers.X) (batch.py:47-48): all three names solve the same QPs."""
+    g = load_golden("c3s_b4_n20_m10_q4_f64")
+    Q, p, G, h, A, b = tens([g[k] for k in ("Q", "p", "G", "h", "A", "b")], grad=False)
+    with emulated():
+        Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(Q, G, A)
+        x, y, z, s = pdipm_b.forward(Q, p, G, h, A, b, Q_LU, S_LU, R, verbose=-1, solver=getattr(pdipm_b.KKTSolvers, solver))
+    assert rel_err(x.numpy(), g["zhat"]).max() < TOL
+    assert rel_err(y.numpy(), g["nu"]).max() < TOL
+
+
+def test_float32_finishing_steps_reach_the_reference_accuracy():
+    """QPFunction in float32: the loop kernel alone lands ~1e-4 from the float64 answer on the benchmark generator
+    (cond(Q) ~ 1e6); with the default finishing steps (refine=None -> 3) it is as close as the reference's own float32
+    run.  Two QPs of the C2 golden pair on the emulator; the distribution over 32 QPs is asserted on the GPU."""
+    g = load_golden("f32pair_c2_b32_n100_m100")
+    B, n, m, q, seed = [int(v) for v in g["shape"]]
+    arrs = [a[:2] if a.size else a for a in problems.prof_qp(B, n, m, q, seed, np.float32)]
+    ref64, ref32 = g["zhat_f64"][:2], g["zhat_f32"][:2]
+    tq = tens(arrs, torch.float32, grad=False)
+    with emulated(256):
+        fast = QPFunction(verbose=-1, refine=0)(*tq)
+        good = QPFunction(verbose=-1)(*tq)
+    e_fast, e_good, e_ref = rel_err(fast.numpy(), ref64), rel_err(good.numpy(), ref64), rel_err(ref32, ref64)
+    assert (e_good < np.maximum(10 * e_ref, 2e-5)).all(), (e_fast, e_good, e_ref)
+    assert (e_good < e_fast).all(), (e_fast, e_good)
