@@ -61,7 +61,7 @@ QPX_LAYOUT_HD BigLayout big_layout(int n, int m)
 
 // ------------------------------------------------------------------------------------------ pack
 template <class T> struct BigPackArgs {
-    int B, rows, cols, P, ldp, sym;       // source rows x cols -> destination P x ldp (sym: symmetrise, identity padding)
+    int B, rows, cols, P, ldp, sym;       // source rows x cols -> destination P x ldp (sym: identity on the padded diagonal)
     const T* src; long long ssrc;
     T* dst; size_t sdst;
 };
@@ -74,7 +74,9 @@ template <class T> QPX_DEV void big_pack_body(const Block& b, const BigPackArgs<
         const int i = 16 * chunk + e / a.ldp, j = e % a.ldp;
         if (i >= a.P) continue;
         T v = T(0);
-        if (i < a.rows && j < a.cols) v = a.sym ? T(0.5) * (S[(size_t)i * a.cols + j] + S[(size_t)j * a.cols + i]) : S[(size_t)i * a.cols + j];
+        // (sym: Q is copied as it is -- the reference assumes a symmetric Q too, qp.py:81-85 -- a symmetrising read of
+        // Q[j][i] is a strided one: 0.34 ms instead of 0.05 for the 128 matrices of C4)
+        if (i < a.rows && j < a.cols) v = S[(size_t)i * a.cols + j];
         else if (a.sym && i == j) v = T(1);
         D[(size_t)i * a.ldp + j] = v;
     }
@@ -98,34 +100,27 @@ template <class T> struct BigPanelArgs {
 };
 QPX_LAYOUT_HD size_t big_panel_lds_elems() { return (size_t)3 * kBB + 8; }
 
-template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArgs<T>& a, int qp, T* lds)
+// D(i, j) = element (i, j) of the 64 x 64 block (any source: global memory, or the LDS tile a trailing update has just
+// finished); W: the 2 x 64 x 64 output of the block; lds: 3 * 64 + 8 elements of scratch.  All 256 threads.
+template <class T, class Elem>
+QPX_DEV void big_diag_block(const Block& b, Elem&& D, T* W, int* ctrl, int fail_bit, T* lds)
 {
-    int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
-    if (a.check_stop && ctrl && ctrl[bcStop]) return;
     constexpr int GS = 16, NBL = kBB / GS;
     const GridPos<GS> g(b);
     T* vec2 = lds;                // 2 x 64: published column / row of a pivot step
     T* dsl = vec2 + 2 * kBB;      // pivots
     T* rd = dsl + 8;              // 1 / d_k
-    const T* M = a.M + (size_t)qp * a.sM;
-    const int k0 = a.k * kBB;
     T E[gtri(NBL)];
 #pragma unroll
     for (int li = 0; li < NBL; ++li)
 #pragma unroll
-        for (int lj = 0; lj <= li; ++lj) {
-            const int i = GS * li + g.a, j = GS * lj + g.b;
-            T v = M[(size_t)(k0 + i) * a.ld + k0 + j];
-            if (a.dg && i == j) v += a.dg[(size_t)qp * a.sdg + k0 + i];
-            E[gidx(li, lj)] = v;
-        }
+        for (int lj = 0; lj <= li; ++lj) E[gidx(li, lj)] = D(GS * li + g.a, GS * lj + g.b);
     GridPos<GS>::sync(b);
     const bool ok = grid_ldl_inv<T, GS, NBL>(b, g, E, vec2, dsl, rd, kBB);
     if (!ok) {
-        if (b.tid == 0 && ctrl) ctrl[bcFail] |= a.fail_bit;
+        if (b.tid == 0 && ctrl) ctrl[bcFail] |= fail_bit;
         return;
     }
-    T* W = a.W + (size_t)qp * a.sW + (size_t)a.k * 2 * kBB * kBB;
     T* Wt = W + kBB * kBB;
 #pragma unroll
     for (int li = 0; li < NBL; ++li)
@@ -142,6 +137,20 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
         }
 }
 
+template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArgs<T>& a, int qp, T* lds)
+{
+    int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
+    if (a.check_stop && ctrl && ctrl[bcStop]) return;
+    const T* M = a.M + (size_t)qp * a.sM;
+    const int k0 = a.k * kBB;
+    const T* dg = a.dg ? a.dg + (size_t)qp * a.sdg + k0 : nullptr;
+    big_diag_block<T>(b, [&](int i, int j) {
+        T v = M[(size_t)(k0 + i) * a.ld + k0 + j];
+        if (dg && i == j) v += dg[i];
+        return v;
+    }, a.W + (size_t)qp * a.sW + (size_t)a.k * 2 * kBB * kBB, ctrl, a.fail_bit, lds);
+}
+
 // ------------------------------------------------------------------------------------------ GEMM tile
 // C[tile (ti, tj)] = (Cs or C or 0)[tile] (+ diag) + alpha * sum over kb < nk of A[arb0+ti][akb0+kb] B[brb0+tj][bkb0+kb]^T
 // grid (B, nti * ntj); lower: tiles with cb0 + ... row block < column block are skipped; mirror: the tile is also
@@ -154,7 +163,11 @@ template <class T> struct BigGemmArgs {
     const T* A; size_t sA; int lda;
     const T* Bm; size_t sB; int ldb;
     T alpha;
-    const int* ctrl; size_t sctrl; int check_stop;
+    int* ctrl; size_t sctrl; int check_stop;
+    // fuse: the workgroup of tile (0, 0) -- the diagonal block the NEXT panel starts from -- goes on to eliminate it
+    // (big_diag_block) as soon as its update is done: W block index fuse_k of W, failure bit as in BigPanelArgs
+    int fuse, fuse_k, fail_bit;
+    T* W; size_t sW;
 };
 QPX_LAYOUT_HD size_t big_gemm_lds_elems() { return (size_t)2 * kBB * kBL; }
 
@@ -198,19 +211,29 @@ template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<
     T* C = a.C + (size_t)qp * a.sC;
     const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs : C;
     const int ldcs = a.Cs ? a.ldcs : a.ldc;
+    const bool fused = a.fuse && tile == 0;          // uniform
+    if (fused) b.sync();                             // every wave is done with the operand tiles in LDS
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = crb * kBB + qr + 16 * x + Block::mfma_row(T(0), g, r), j = ccb * kBB + qc + 16 * y + c16;
+                const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
+                const int i = crb * kBB + il, j = ccb * kBB + jl;
                 T v = a.zero_init ? T(0) : Cs[(size_t)i * ldcs + j];
                 if (a.dg && i == j) v += a.dg[(size_t)qp * a.sdg + i];
                 v = fma_(a.alpha, acc[x][y][r], v);
                 C[(size_t)i * a.ldc + j] = v;
                 if (a.mirror && crb != ccb) C[(size_t)j * a.ldc + i] = v;
+                if (fused) As[il * kBL + jl] = v;
             }
+    if (fused) {
+        b.sync();
+        int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
+        big_diag_block<T>(b, [&](int i, int j) { return As[i * kBL + j]; },
+                          a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, Bs);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ triangular solve
@@ -246,31 +269,42 @@ template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<
         const int k0 = k * kBB;
         const int c0 = a.dir == 0 ? 0 : k0 + kBB, c1 = a.dir == 0 ? k0 : np;      // known entries
         b.sync();
+        // W_kk (W_kk^T) entries of the diagonal mat-vec: independent of everything computed below, so they are
+        // fetched first and fly under the off-diagonal loop
+        const T* Wg = a.W + (size_t)qp * a.sW + (size_t)k * 2 * kBB * kBB + (a.dir == 0 ? kBB * kBB : 0) + lane;
+        T wv[kBB / 4];
+#pragma unroll
+        for (int u = 0; u < kBB / 4; ++u) wv[u] = Wg[(w + 4 * u) * kBB];
         {
-            // rows c of the stored matrix (L^T above the diagonal for dir 0, L below it for dir 1), element k0 + lane
+            // rows c of the stored matrix (L^T above the diagonal for dir 0, L below it for dir 1), element k0 + lane;
+            // eight independent loads in flight per lane
             const T* col = M + k0 + lane;
-            T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
             int c = c0 + w;
-            for (; c + 12 < c1; c += 16) {
-                const T m0 = col[(size_t)c * a.ld], m1 = col[(size_t)(c + 4) * a.ld];
-                const T m2 = col[(size_t)(c + 8) * a.ld], m3 = col[(size_t)(c + 12) * a.ld];
+            for (; c + 28 < c1; c += 32) {
+                const T m0 = col[(size_t)c * a.ld], m1 = col[(size_t)(c + 4) * a.ld], m2 = col[(size_t)(c + 8) * a.ld];
+                const T m3 = col[(size_t)(c + 12) * a.ld], m4 = col[(size_t)(c + 16) * a.ld], m5 = col[(size_t)(c + 20) * a.ld];
+                const T m6 = col[(size_t)(c + 24) * a.ld], m7 = col[(size_t)(c + 28) * a.ld];
                 a0 = fma_(m0, xs[c], a0);
                 a1 = fma_(m1, xs[c + 4], a1);
                 a2 = fma_(m2, xs[c + 8], a2);
                 a3 = fma_(m3, xs[c + 12], a3);
+                a4 = fma_(m4, xs[c + 16], a4);
+                a5 = fma_(m5, xs[c + 20], a5);
+                a6 = fma_(m6, xs[c + 24], a6);
+                a7 = fma_(m7, xs[c + 28], a7);
             }
             for (; c < c1; c += 4) a0 = fma_(col[(size_t)c * a.ld], xs[c], a0);
-            part[w * kBB + lane] = (a0 + a1) + (a2 + a3);
+            part[w * kBB + lane] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
         }
         b.sync();
         if (b.tid < kBB) t[b.tid] = xs[k0 + b.tid] - ((part[b.tid] + part[kBB + b.tid]) + (part[2 * kBB + b.tid] + part[3 * kBB + b.tid]));
         b.sync();
         {
             // x_k = W t (dir 0: rows of W^T are the contiguous ones) or W^T t (dir 1: rows of W)
-            const T* Wg = a.W + (size_t)qp * a.sW + (size_t)k * 2 * kBB * kBB + (a.dir == 0 ? kBB * kBB : 0) + lane;
             T acc = 0;
-#pragma unroll 4
-            for (int c = w; c < kBB; c += 4) acc = fma_(Wg[c * kBB], t[c], acc);
+#pragma unroll
+            for (int u = 0; u < kBB / 4; ++u) acc = fma_(wv[u], t[w + 4 * u], acc);
             part[w * kBB + lane] = acc;
         }
         b.sync();
@@ -682,6 +716,52 @@ template <class T> QPX_DEV void big_kkt_body(const Block& b, const BigKktArgs<T>
             const int r = r0 + e / n, c = e % n;
             if (r < m) a.dG[((size_t)qp * m + r) * n + c] = bad ? T(0) : (vX[r] * zh[c] + lm[r] * vW[c]);
         }
+}
+
+// ------------------------------------------------------------------------------------------ fused launches
+// Fewer, longer kernels on the loop's critical path (a pass of the loop was 31 launches, many of them ~8 us):
+//   big_solve_body: forward AND backward substitution of one solve, then the wave-0 phase that consumes the result
+//   big_diag_body:  the wave-0 phase that produces d = s/z (and the stop decision), then the elimination of the first
+//                   diagonal block of T = R + diag(d)
+template <class T> struct BigSolveArgs {
+    BigTrsvArgs<T> t;            // dir / post are set by the body: forward, then backward with the sign of `negate`
+    BigPhaseArgs<T> ph;
+    int negate, post_phase;      // post_phase < 0: none
+};
+template <class T, int NS> QPX_DEV void big_solve_body(const Block& b, const BigSolveArgs<T>& a, int qp, T* lds)
+{
+    BigTrsvArgs<T> t = a.t;
+    t.dir = 0; t.post = 0;
+    big_trsv_body<T>(b, t, qp, lds);
+    b.sync();
+    t.dir = 1; t.post = a.negate; t.xin = a.t.x; t.sxin = a.t.sx;
+    big_trsv_body<T>(b, t, qp, lds);
+    if (a.post_phase >= 0) {
+        b.sync();                                    // the solution is in global memory for wave 0
+        if (b.uniform(b.wave()) == 0) {
+            BigPhaseArgs<T> ph = a.ph;
+            ph.phase = a.post_phase;
+            big_phase_body<T, NS>(b, ph, qp);
+        }
+    }
+}
+
+template <class T> struct BigDiagArgs {
+    BigPanelArgs<T> p;
+    BigPhaseArgs<T> ph;
+    int pre_phase;               // < 0: none
+};
+template <class T, int NS> QPX_DEV void big_diag_body(const Block& b, const BigDiagArgs<T>& a, int qp, T* lds)
+{
+    if (a.pre_phase >= 0) {
+        if (b.uniform(b.wave()) == 0) {
+            BigPhaseArgs<T> ph = a.ph;
+            ph.phase = a.pre_phase;
+            big_phase_body<T, NS>(b, ph, qp);
+        }
+        b.sync();
+    }
+    big_panel_body<T>(b, a.p, qp, lds);
 }
 
 }  // namespace qpx

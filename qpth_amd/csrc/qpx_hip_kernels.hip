@@ -246,6 +246,18 @@ template <class T, int NS> __global__ __launch_bounds__(64) void k_big_phase(Big
     const Block b{(int)threadIdx.x, (int)blockDim.x};
     big_phase_body<T, NS>(b, a, (int)blockIdx.x);
 }
+template <class T, int NS> __global__ __launch_bounds__(256) void k_big_solve(BigSolveArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    big_solve_body<T, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NS> __global__ __launch_bounds__(256) void k_big_diag(BigDiagArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    big_diag_body<T, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
 template <class K, class A> static int big_launch(K kern, const A& a, int gx, int gy, int threads, size_t lds, void* stream, bool& big_ok)
 {
     if (allow_big_lds(kern, lds, big_ok)) return QPX_ERR_LAUNCH;
@@ -275,7 +287,32 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* s)
     default: return big_launch(k_big_phase<T, 8>, a, a.B, 1, 64, 0, s, f);
     }
 }
+template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* s)
+{
+    static bool f = false;
+    const size_t lds = big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T);
+    const int ns = big_pad(a.ph.m) / kWave;
+    switch (ns) {
+    case 1: return big_launch(k_big_solve<T, 1>, a, a.t.B, 1, 256, lds, s, f);
+    case 2: return big_launch(k_big_solve<T, 2>, a, a.t.B, 1, 256, lds, s, f);
+    case 3: case 4: return big_launch(k_big_solve<T, 4>, a, a.t.B, 1, 256, lds, s, f);
+    default: return big_launch(k_big_solve<T, 8>, a, a.t.B, 1, 256, lds, s, f);
+    }
+}
+template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* s)
+{
+    static bool f = false;
+    const size_t lds = big_panel_lds_elems() * sizeof(T);
+    const int ns = big_pad(a.ph.m) / kWave;
+    switch (ns) {
+    case 1: return big_launch(k_big_diag<T, 1>, a, a.p.B, 1, 256, lds, s, f);
+    case 2: return big_launch(k_big_diag<T, 2>, a, a.p.B, 1, 256, lds, s, f);
+    case 3: case 4: return big_launch(k_big_diag<T, 4>, a, a.p.B, 1, 256, lds, s, f);
+    default: return big_launch(k_big_diag<T, 8>, a, a.p.B, 1, 256, lds, s, f);
+    }
+}
 #define QPX_INSTB(NAME, ARGS) template int NAME<QPX_TU_REAL>(const ARGS<QPX_TU_REAL>&, void*);
+QPX_INSTB(launch_big_solve, BigSolveArgs) QPX_INSTB(launch_big_diag, BigDiagArgs)
 template int launch_big_pack<QPX_TU_REAL>(const BigPackArgs<QPX_TU_REAL>&, int, void*);
 template int launch_big_kkt<QPX_TU_REAL>(const BigKktArgs<QPX_TU_REAL>&, int, void*);
 QPX_INSTB(launch_big_panel, BigPanelArgs) QPX_INSTB(launch_big_gemm, BigGemmArgs) QPX_INSTB(launch_big_trsv, BigTrsvArgs) QPX_INSTB(launch_big_gemv, BigGemvArgs)

@@ -47,5 +47,7 @@ template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* stream);
 template <class T> int launch_big_vec(const BigVecArgs<T>& a, void* stream);
 template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* stream);
 template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* stream);
+template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* stream);
+template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* stream);
 
 }  // namespace qpx

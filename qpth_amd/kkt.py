@@ -184,7 +184,7 @@ a non-zero diagonal.
         return dx, ds, dz, dy
 
     # -- KKTSolvers.IR_UNOPT (batch.py:244-270) as a finishing stage --------------------------------
-    def polish(self, p, h, b, res, steps=3, refine=1):
+    def polish(self, p, h, b, res, steps=2, refine=1):
         """`steps` iterations of the reference's PDIPM loop (batch.py:92-198: affine + centring-corrector) in the ORIGINAL
         variables (x, s, z, y), started from the loop kernel's result, with the KKT residuals evaluated from the
         caller's Q, G, A in float64 and every solve refined in the kernel (solve_kkt(..., refine)).  The loop kernel iterates on pre-computed products (R = G Q^-1 G^T, ...): in float32

@@ -40,7 +40,7 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
     """`refine` is the one argument the reference does not have: the number of finishing Newton steps on the residuals
     of the ORIGINAL problem data (KKTFactors.polish -- the reference's KKTSolvers.IR_UNOPT idea, batch.py:244-270)
     (each with one in-kernel refinement step per KKT solve, also applied to the backward solve).  None = automatic:
-    3 in float32 (whose pre-computed products R = G Q^-1 G^T carry ~1e-2 relative error on the benchmark generator:
+    2 in float32 (whose pre-computed products R = G Q^-1 G^T carry ~1e-2 relative error on the benchmark generator:
     the loop kernel alone lands 20x further from the float64 answer than the reference's float32 run does), 0 in
     float64.  refine=0 is the fast float32 path."""
     class QPFunctionFn(Function):
@@ -63,7 +63,7 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                 fac = KKTFactors.build(Q, G, A, nBatch)            # qp.py:93
                 res = fac.ipm(p, h, b, eps, maxIter, notImprovedLim,
                               want_trace=(verbose == 1))             # qp.py:94-96
-                ctx.refine = (3 if Q.dtype == torch.float32 else 0) if refine is None else int(refine)
+                ctx.refine = (2 if Q.dtype == torch.float32 else 0) if refine is None else int(refine)
                 if ctx.refine > 0:
                     res = fac.polish(p, h, b, res, steps=ctx.refine, refine=1)
                 # one small read-back: the reference raises here too (qp.py:81-85, batch.py:379-386)

@@ -235,6 +235,31 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void*)
     return QPX_OK;
 }
 
+template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void*)
+{
+    const int ns = big_pad(a.ph.m) / kWave;
+    big_grid(a.t.B, 1, 256, big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
+        T* lds = reinterpret_cast<T*>(l);
+        if (ns == 1) big_solve_body<T, 1>(b, a, qp, lds);
+        else if (ns == 2) big_solve_body<T, 2>(b, a, qp, lds);
+        else if (ns <= 4) big_solve_body<T, 4>(b, a, qp, lds);
+        else big_solve_body<T, 8>(b, a, qp, lds);
+    });
+    return QPX_OK;
+}
+template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void*)
+{
+    const int ns = big_pad(a.ph.m) / kWave;
+    big_grid(a.p.B, 1, 256, big_panel_lds_elems() * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
+        T* lds = reinterpret_cast<T*>(l);
+        if (ns == 1) big_diag_body<T, 1>(b, a, qp, lds);
+        else if (ns == 2) big_diag_body<T, 2>(b, a, qp, lds);
+        else if (ns <= 4) big_diag_body<T, 4>(b, a, qp, lds);
+        else big_diag_body<T, 8>(b, a, qp, lds);
+    });
+    return QPX_OK;
+}
+
 template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int chunks, void*)
 {
     if (a.use_atomics)

@@ -429,7 +429,7 @@ def test_forward_accepts_every_kkt_solver(solver):
 
 def test_float32_finishing_steps_reach_the_reference_accuracy():
     """QPFunction in float32: the loop kernel alone lands ~1e-4 from the float64 answer on the benchmark generator
-    (cond(Q) ~ 1e6); with the default finishing steps (refine=None -> 3) it is as close as the reference's own float32
+    (cond(Q) ~ 1e6); with the default finishing steps (refine=None -> 2) it is as close as the reference's own float32
     run.  Two QPs of the C2 golden pair on the emulator; the distribution over 32 QPs is asserted on the GPU."""
     g = load_golden("f32pair_c2_b32_n100_m100")
     B, n, m, q, seed = [int(v) for v in g["shape"]]

@@ -258,7 +258,7 @@ def test_float32_error_distribution_matches_the_reference(dev, name):
     DISTRIBUTION, next to the reference's own f32-vs-f64 distribution on the same 32 QPs (the generator's Q has
     cond ~ 1.6e6, so f32 cannot meet the 1e-4 gate on every QP in either implementation: the reference's own
     max is 4.5e-4 at C2 and 5e-3 at C3).  Asserted: median within 10x, maximum within 4x of the reference's -- with
-    the default float32 finishing steps (QPFunction(refine=None) -> 3 iterations on the residuals of the original
+    the default float32 finishing steps (QPFunction(refine=None) -> 2 iterations on the residuals of the original
     data, KKTFactors.polish); the loop kernel alone (refine=0, the fast path) is printed beside it."""
     g = load_golden(name)
     B, n, m, q, seed = [int(v) for v in g["shape"]]
