@@ -32,6 +32,7 @@ Tables of the reference's timing scripts (one JSON line per row, after the headl
                         pre_factor_kkt + forward only
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import os
@@ -338,6 +339,33 @@ def main():
                     "algorithmic_flops_per_launch": ipm_flops,
                     "algorithmic_bytes_per_launch": ipm_bytes, "hbm_frac": ipm_bytes / t_ipm / HBM_PEAK,
                     "launch_ms": t_ipm * 1e3, "kernel_source_digest": kernel_source_digest()}
+
+        # Large-QP family (C4): a forward is ~400 stream-ordered launches; the dominant kernel is the MFMA tile GEMM
+        # (k_big_gemm, ~70 % of the time).  Its largest launch, R = Zt Zt^T of the pre-factorisation, is re-issued
+        # alone through the measurement hook and priced against the f64/f32 matrix-core peak: m^2 n flops per QP
+        # (one triangle of the symmetric product), Zt read + R written per QP.
+        lib = _lib.hip()
+        code = _lib.QPX_F64 if args.dtype == "f64" else _lib.QPX_F32
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        blob_ptr = ctypes.c_void_p(fac.blob.data_ptr())
+        with fac._knob():
+            is_big = lib.dll.qpx_big_gemm_r(code, B, n, m, q, blob_ptr, ctypes.c_void_p(stream)) == 0
+        if is_big:
+            def gemm_r():
+                with fac._knob():
+                    lib.check(lib.dll.qpx_big_gemm_r(code, B, n, m, q, blob_ptr, ctypes.c_void_p(stream)))
+            t_gemm = time_launches(gemm_r, 20)
+            g_flops = float(m) * m * n * B
+            g_bytes = float(m * n + m * m) * w * B
+            roofline = {"kernel": "k_big_gemm, launch R = Zt Zt^T of the large-QP pre-factorisation (one launch, the whole batch)",
+                        "bound": "mfma", "achieved": g_flops / t_gemm / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                        "frac": g_flops / t_gemm / peak, "traffic": None,
+                        "traffic_source": "no PMC pass for this launch",
+                        "algorithmic_flops_per_launch": g_flops, "algorithmic_bytes_per_launch": g_bytes,
+                        "hbm_frac": g_bytes / t_gemm / HBM_PEAK, "launch_ms": t_gemm * 1e3,
+                        "kernel_source_digest": kernel_source_digest(),
+                        "whole_loop": {"what": "all launches of qpx_ipm together, algorithmic flops of the loop / their time",
+                                       "achieved": achieved / 1e12, "frac": achieved / peak}}
 
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1 and not args.shared:      # reported at N = 1 only

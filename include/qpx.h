@@ -91,6 +91,10 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4; by default the library picks by dtype, size and batch.
+ * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
+ * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
+ * synchronisation), 0 = automatic (4 from 64 QPs, 2 from 32); bits 20..27 = initial stagger between the side
+ * streams in units of 16 us.
  * The knob must not change between qpx_pre_factor and the calls that consume its factors (it selects the
  * layout of `factors` too: ask qpx_factor_elems after setting it).
  * Returns the previous value. */
@@ -100,6 +104,11 @@ int qpx_get_ipm_variant(void);      /* the calling thread's current value */
 /* May a batch whose Q, G, A are shared be served by ONE factor blob (qpx_pre_factor with B = 1, consumers
  * with sfac = 0)?  Always for the thread-grid / tile kernels; for the workgroup kernels only if qpx_fits_lds. */
 int qpx_can_share_factors(int dtype, int n, int m, int q);
+
+/* Measurement hook (bench.py): re-issues the largest GEMM of the large-QP pre-factorisation, R = Zt Zt^T, on the
+ * blobs qpx_pre_factor wrote (idempotent: R is rewritten with the same values), as ONE launch on `stream`, so that
+ * it can be bracketed by events on its own.  QPX_ERR_UNSUPPORTED when (dtype, n, m, q) is not served by that family. */
+int qpx_big_gemm_r(int dtype, int B, int n, int m, int q, void* factors, qpx_stream_t stream);
 
 /* pre_factor_kkt(Q, G, A) */
 int qpx_pre_factor(int dtype, int B, int n, int m, int q,

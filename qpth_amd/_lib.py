@@ -33,6 +33,7 @@ _SIGNATURES = {
     "qpx_set_ipm_variant": (_i, [_i]),
     "qpx_get_ipm_variant": (_i, []),
     "qpx_can_share_factors": (_i, [_i, _i, _i, _i]),
+    "qpx_big_gemm_r": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
     "qpx_pre_factor": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "qpx_ipm": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _d, _i, _i, _i,
                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -20,11 +20,15 @@
 // The trailing updates C -= A B^T run on v_mfma_f64_16x16x4 (f32: v_mfma_f32_16x16x4): a workgroup owns a 64 x 64
 // tile of C, each of its four waves a 32 x 32 quadrant (four accumulator tiles), operands staged through LDS.
 #pragma once
+#include <type_traits>
+
 #include "qpx_grid.h"
+#include "qpx_tile.h"
 
 namespace qpx {
 
 constexpr int kBB = 64;          // block order
+constexpr int kMaxSide = 3;          // side streams the host may spread the parts of a batch over (qpx_api.inc: big_split)
 constexpr int kBL = kBB + 2;     // LDS row stride of a staged block (elements): 2-way bank conflicts at most
 QPX_LAYOUT_HD int big_pad(int x) { return (x + kBB - 1) / kBB * kBB; }
 
@@ -97,13 +101,17 @@ template <class T> struct BigPanelArgs {
     int* ctrl; size_t sctrl;              // per-QP control words (elements of int); may be null
     int fail_bit;                         // status bit OR-ed into ctrl[bcFail] when a pivot breaks down
     int check_stop;                       // skip QPs whose ctrl[bcStop] is set (loop factorisations)
+    int tile;                             // f64: eliminate on the matrix cores (big_diag_block_tile)
 };
-QPX_LAYOUT_HD size_t big_panel_lds_elems() { return (size_t)3 * kBB + 8; }
+// LDS of a diagonal-block elimination: thread-grid form 3 * 64 + 8; matrix-core form (f64) the staged result
+// (64 x 66) + the tile routine's scratch + 64 reciprocal pivots
+QPX_LAYOUT_HD size_t big_diag_scratch_elems() { return TileMat<kBB / 16, 1>::scratch_elems() + kBB + 8; }
+QPX_LAYOUT_HD size_t big_panel_lds_elems() { return (size_t)kBB * kBL + big_diag_scratch_elems(); }
 
 // D(i, j) = element (i, j) of the 64 x 64 block (any source: global memory, or the LDS tile a trailing update has just
 // finished); W: the 2 x 64 x 64 output of the block; lds: 3 * 64 + 8 elements of scratch.  All 256 threads.
 template <class T, class Elem>
-QPX_DEV void big_diag_block(const Block& b, Elem&& D, T* W, int* ctrl, int fail_bit, T* lds)
+QPX_DEV void big_diag_block_grid(const Block& b, Elem&& D, T* W, int* ctrl, int fail_bit, T* lds)
 {
     constexpr int GS = 16, NBL = kBB / GS;
     const GridPos<GS> g(b);
@@ -137,6 +145,80 @@ QPX_DEV void big_diag_block(const Block& b, Elem&& D, T* W, int* ctrl, int fail_
         }
 }
 
+// The same elimination on the matrix cores (f64): ONE wave holds the lower triangle as ten 16 x 16 accumulator tiles
+// and runs the rank-4 blocked ldl_inv of the tile loop kernel (qpx_tile.h, TileMat<4, 1>: 16 panels, wave-level
+// ordering only, no workgroup barrier per pivot); the other waves zero the upper tiles of the staged result and
+// then help to write W and W^T out coalesced.  stage: 64 x kBL elements of LDS -- MAY be the array D reads (wave 0
+// is done with D before it writes, the other waves only touch tiles above the diagonal, which D is never asked
+// for); scr: big_diag_scratch_elems().  All 256 threads.
+template <class Elem>
+QPX_DEV void big_diag_block_tile(const Block& b, Elem&& D, double* W, int* ctrl, int fail_bit, double* stage, double* scr)
+{
+    using TM = TileMat<kBB / 16, 1>;
+    double* rd = scr + TM::scratch_elems();
+    double* flag = rd + kBB;
+    const int w = b.uniform(b.wave());
+    if (w == 0) {
+        const typename TM::Pos p(b);
+        typename TM::Regs E;
+#pragma unroll
+        for (int pp = 0; pp < TM::NPOS; ++pp) {
+            const int I = TM::rowof(pp, 0);
+#pragma unroll
+            for (int J = 0; J < TM::psize(pp); ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) E.e[TM::slot(pp, J)][r] = D(16 * I + p.g + 4 * r, 16 * J + p.c);
+        }
+        const bool ok = TM::ldl_inv(b, p, E, scr, rd, kBB);
+        if (p.lane == 0) flag[0] = ok ? 1.0 : 0.0;
+        if (ok) {
+#pragma unroll
+            for (int pp = 0; pp < TM::NPOS; ++pp) {
+                const int I = TM::rowof(pp, 0);
+#pragma unroll
+                for (int J = 0; J < TM::psize(pp); ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * I + p.g + 4 * r, j = 16 * J + p.c;
+                        const double rs = sqrt_(rd[i]);
+                        stage[i * kBL + j] = (j < i) ? E.e[TM::slot(pp, J)][r] * rs : (j == i ? rs : 0.0);
+                    }
+            }
+        }
+    } else {
+        // strictly upper tiles (I < J): 6 tiles x 256 entries over 192 threads
+        for (int e = b.tid - kWave; e < 6 * 256; e += b.nt - kWave) {
+            const int t = e >> 8, o = e & 255;
+            const int I = t < 3 ? 0 : (t < 5 ? 1 : 2), J = t < 3 ? t + 1 : (t < 5 ? t - 1 : 3);
+            stage[(16 * I + (o >> 4)) * kBL + 16 * J + (o & 15)] = 0.0;
+        }
+    }
+    b.sync();
+    if (flag[0] == 0.0) {
+        if (b.tid == 0 && ctrl) ctrl[bcFail] |= fail_bit;
+        return;
+    }
+    double* Wt = W + kBB * kBB;
+    for (int e = b.tid; e < kBB * kBB; e += b.nt) {
+        const int i = e >> 6, j = e & 63;
+        W[e] = stage[i * kBL + j];
+        Wt[e] = stage[j * kBL + i];
+    }
+}
+
+// tile: the matrix-core form when T is double (stage / scr as above); otherwise the thread-grid form with scr as its scratch
+template <class T, class Elem>
+QPX_DEV void big_diag_block(const Block& b, Elem&& D, T* W, int* ctrl, int fail_bit, T* stage, T* scr, int tile)
+{
+    if constexpr (std::is_same<T, double>::value) {
+        if (tile) {
+            big_diag_block_tile(b, D, W, ctrl, fail_bit, stage, scr);
+            return;
+        }
+    }
+    big_diag_block_grid<T>(b, D, W, ctrl, fail_bit, scr);
+}
+
 template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArgs<T>& a, int qp, T* lds)
 {
     int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
@@ -144,11 +226,24 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
     const T* M = a.M + (size_t)qp * a.sM;
     const int k0 = a.k * kBB;
     const T* dg = a.dg ? a.dg + (size_t)qp * a.sdg + k0 : nullptr;
+    T* W = a.W + (size_t)qp * a.sW + (size_t)a.k * 2 * kBB * kBB;
+    if (std::is_same<T, double>::value && a.tile) {
+        // the matrix-core form reads the block with one wave: bring it into LDS with all four first (coalesced rows)
+        for (int e = b.tid; e < kBB * kBB; e += b.nt) {
+            const int i = e >> 6, j = e & 63;
+            T v = M[(size_t)(k0 + i) * a.ld + k0 + j];
+            if (dg && i == j) v += dg[i];
+            lds[i * kBL + j] = v;
+        }
+        b.sync();
+        big_diag_block<T>(b, [&](int i, int j) { return lds[i * kBL + j]; }, W, ctrl, a.fail_bit, lds, lds + kBB * kBL, 1);
+        return;
+    }
     big_diag_block<T>(b, [&](int i, int j) {
         T v = M[(size_t)(k0 + i) * a.ld + k0 + j];
         if (dg && i == j) v += dg[i];
         return v;
-    }, a.W + (size_t)qp * a.sW + (size_t)a.k * 2 * kBB * kBB, ctrl, a.fail_bit, lds);
+    }, W, ctrl, a.fail_bit, lds, lds + kBB * kBL, 0);
 }
 
 // ------------------------------------------------------------------------------------------ GEMM tile
@@ -166,8 +261,9 @@ template <class T> struct BigGemmArgs {
     int* ctrl; size_t sctrl; int check_stop;
     // fuse: the workgroup of tile (0, 0) -- the diagonal block the NEXT panel starts from -- goes on to eliminate it
     // (big_diag_block) as soon as its update is done: W block index fuse_k of W, failure bit as in BigPanelArgs
-    int fuse, fuse_k, fail_bit;
+    int fuse, fuse_k, fail_bit, tile;
     T* W; size_t sW;
+    int no_swizzle;              // A/B: plain (qp, tile) grid instead of the XCD-aware one (launcher only)
 };
 QPX_LAYOUT_HD size_t big_gemm_lds_elems() { return (size_t)2 * kBB * kBL; }
 
@@ -190,14 +286,44 @@ template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[x][y][r] = T(0);
+    T* C = a.C + (size_t)qp * a.sC;
+    const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs : C;
+    const int ldcs = a.Cs ? a.ldcs : a.ldc;
+    // The workgroup's life is a chain of memory latencies (operands of a k-block -> LDS -> matrix cores, then the
+    // tile of C): the tile of C is requested first, and the operands of k-block kb + 1 are requested (into
+    // registers) before the matrix instructions of k-block kb are issued, so both fly under them.
+    T cs[2][2][4];
+    if (!a.zero_init) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = crb * kBB + qr + 16 * x + Block::mfma_row(T(0), g, r), j = ccb * kBB + qc + 16 * y + c16;
+                    cs[x][y][r] = Cs[(size_t)i * ldcs + j];
+                }
+    }
+    constexpr int kPer = kBB * kBB / 256;             // staged elements per thread and operand (256 threads)
+    T pa[kPer], pb[kPer];
+    const int sr = b.tid >> 6, sk = b.tid & 63;        // a wave stages one row (64 consecutive k) per step
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            pa[u] = Ag[(size_t)(sr + 4 * u) * a.lda + (a.akb0 + kb) * kBB + sk];
+            pb[u] = Bg[(size_t)(sr + 4 * u) * a.ldb + (a.bkb0 + kb) * kBB + sk];
+        }
+    };
+    fetch(0);
     for (int kb = 0; kb < a.nk; ++kb) {
         b.sync();
-        for (int e = b.tid; e < kBB * kBB; e += b.nt) {
-            const int r = e >> 6, kk = e & 63;
-            As[kk * kBL + r] = Ag[(size_t)r * a.lda + (a.akb0 + kb) * kBB + kk];
-            Bs[kk * kBL + r] = Bg[(size_t)r * a.ldb + (a.bkb0 + kb) * kBB + kk];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            As[sk * kBL + sr + 4 * u] = pa[u];
+            Bs[sk * kBL + sr + 4 * u] = pb[u];
         }
         b.sync();
+        if (kb + 1 < a.nk) fetch(kb + 1);
 #pragma unroll 4
         for (int s = 0; s < kBB / 4; ++s) {
             const T a0 = As[(4 * s + g) * kBL + qr + c16], a1 = As[(4 * s + g) * kBL + qr + 16 + c16];
@@ -208,9 +334,6 @@ template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<
             b.mfma16x16x4(a1, b1, acc[1][1]);
         }
     }
-    T* C = a.C + (size_t)qp * a.sC;
-    const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs : C;
-    const int ldcs = a.Cs ? a.ldcs : a.ldc;
     const bool fused = a.fuse && tile == 0;          // uniform
     if (fused) b.sync();                             // every wave is done with the operand tiles in LDS
 #pragma unroll
@@ -221,7 +344,7 @@ template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<
             for (int r = 0; r < 4; ++r) {
                 const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
                 const int i = crb * kBB + il, j = ccb * kBB + jl;
-                T v = a.zero_init ? T(0) : Cs[(size_t)i * ldcs + j];
+                T v = a.zero_init ? T(0) : cs[x][y][r];
                 if (a.dg && i == j) v += a.dg[(size_t)qp * a.sdg + i];
                 v = fma_(a.alpha, acc[x][y][r], v);
                 C[(size_t)i * a.ldc + j] = v;
@@ -232,7 +355,7 @@ template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<
         b.sync();
         int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
         big_diag_block<T>(b, [&](int i, int j) { return As[i * kBL + j]; },
-                          a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, Bs);
+                          a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, As, Bs, a.tile);
     }
 }
 

@@ -7,4 +7,63 @@
 #include "../../include/qpx.h"
 #include "qpx_launch.h"
 
+namespace qpx {
+
+// One pool of side streams + events per (host thread, device), created on first use and kept for the life of the
+// thread.  Fork / join are event record + stream wait: stream-ordered, legal under stream capture, no host sync.
+struct SidePool {
+    hipStream_t s[kMaxSide];
+    hipEvent_t fork, done[kMaxSide];
+    bool ok = false;
+};
+constexpr int kMaxDev = 16;
+static thread_local SidePool g_side[kMaxDev];
+
+__global__ void k_stream_delay(long long ticks)
+{
+    // wall_clock64: constant 100 MHz; bounded above by the host (<= 10 ms), so it always terminates
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+int stream_fork(void* caller, int nside, void** side, int delay_us)
+{
+    int dev = 0;
+    if (nside < 1 || nside > kMaxSide || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
+    SidePool& p = g_side[dev];
+    if (!p.ok) {
+        if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return QPX_ERR_LAUNCH;
+        for (int i = 0; i < kMaxSide; ++i)
+            if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) != hipSuccess)
+                return QPX_ERR_LAUNCH;
+        p.ok = true;
+    }
+    if (hipEventRecord(p.fork, (hipStream_t)caller) != hipSuccess) return QPX_ERR_LAUNCH;
+    for (int i = 0; i < nside; ++i) {
+        if (hipStreamWaitEvent(p.s[i], p.fork, 0) != hipSuccess) return QPX_ERR_LAUNCH;
+        if (delay_us > 0) {
+            long long us = (long long)delay_us * (i + 1);
+            if (us > 10000) us = 10000;
+            hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, p.s[i], us * 100);
+        }
+        side[i] = (void*)p.s[i];
+    }
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+
+int stream_join(void* caller, int nside, void* const* side)
+{
+    int dev = 0;
+    if (nside < 1 || nside > kMaxSide || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
+    SidePool& p = g_side[dev];
+    for (int i = 0; i < nside; ++i) {
+        if (hipEventRecord(p.done[i], (hipStream_t)side[i]) != hipSuccess) return QPX_ERR_LAUNCH;
+        if (hipStreamWaitEvent((hipStream_t)caller, p.done[i], 0) != hipSuccess) return QPX_ERR_LAUNCH;
+    }
+    return QPX_OK;
+}
+
+}  // namespace qpx
+
 #include "qpx_api.inc"

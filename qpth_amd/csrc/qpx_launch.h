@@ -49,5 +49,12 @@ template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* stre
 template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* stream);
 template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* stream);
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* stream);
+// Side streams for the parts of a batch the large-QP family works on concurrently (qpx_api.inc: big_split).
+// stream_fork: side[0 .. nside) = streams of the calling host thread's pool, made to wait (event) for everything
+// enqueued on `caller` so far; stream_join: `caller` waits (events) for everything enqueued on them.  Neither
+// synchronises the host.  delay_us > 0: side stream i first sleeps i * delay_us (one idle wave), which sets the
+// parts out of phase with each other.
+int stream_fork(void* caller, int nside, void** side, int delay_us);
+int stream_join(void* caller, int nside, void* const* side);
 
 }  // namespace qpx

@@ -269,6 +269,14 @@ template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int 
     return QPX_OK;
 }
 
+// side streams: launches are synchronous here, so the parts of a batch simply run one after the other
+int stream_fork(void* caller, int nside, void** side, int)
+{
+    for (int i = 0; i < nside; ++i) side[i] = caller;
+    return QPX_OK;
+}
+int stream_join(void*, int, void* const*) { return QPX_OK; }
+
 }  // namespace qpx
 
 #include "qpx_api.inc"

@@ -280,18 +280,20 @@ def test_edge_shapes_match_the_reference(name):
 
 
 # ---------------------------------------------------------------- round 2: the large-QP family (qpx_big.h)
-@pytest.mark.parametrize("shape,dtype", [((1, 66, 70), torch.float64), ((1, 20, 70), torch.float32)])
-def test_large_qp_family(shape, dtype):
+@pytest.mark.parametrize("shape,dtype,knob", [((1, 66, 70), torch.float64, 3), ((1, 20, 70), torch.float32, 3),
+                                              ((3, 20, 70), torch.float64, 3 + (3 << 16))])
+def test_large_qp_family(shape, dtype, knob):
     """BASELINE.json configs[3] runs through a multi-kernel family (blocked Cholesky / triangular solves / MFMA trailing
     updates on 64 x 64 blocks, matrices in HBM).  Forced here (knob 3) at sizes of two and three blocks so that the
-    blocked code paths run on the emulator: zhat and every gradient against the oracle."""
+    blocked code paths run on the emulator: zhat and every gradient against the oracle.  Third case: the batch
+    split into three parts (knob bits 16..19), as the host does on the GPU to overlap the parts on side streams."""
     B, n, m = shape
     f32 = dtype == torch.float32
     arrs = problems.prof_qp(B, n, m, 0, seed=3, dtype=np.float32 if f32 else np.float64)
     arrs64 = problems.prof_qp(B, n, m, 0, seed=3)
     dl = np.random.RandomState(0).randn(B, n)
     x, y, lam, s, grads, info = orc.qp_forward_backward(*arrs64, dl_dz=dl, per_qp=True, stall_policy=2)
-    z, mine = run_qpf(arrs, dl.astype(arrs[0].dtype), dtype=dtype, threads=256, variant=3)
+    z, mine = run_qpf(arrs, dl.astype(arrs[0].dtype), dtype=dtype, threads=256, variant=knob)
     tol = 5e-3 if f32 else TOL
     assert rel_err(z, x).max() < tol
     for a_, r_ in zip(mine, grads):
