@@ -90,6 +90,43 @@ struct Block {
         return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false));
     }
 
+    // value of `v` held by lane K of this lane's row of 16 lanes: DPP row_newbcast, the one DPP pattern the
+    // f64 ALU of gfx90a+ takes (v_mov_b64_dpp; the compiler folds it into v_rcp_f64_dpp and friends)
+    template <int K> QPX_DEV double row_bcast(double v) const
+    {
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true);
+    }
+    // a[j] += (a[j] of lane K of this row of 16) * m for every j != K: ONE instruction per element
+    // (v_fmac_f64_dpp, src0 through the row broadcast).  The compiler does not form it from update_dpp + fma
+    // (it keeps a v_mov_b64_dpp per element), hence the assembly.  Hazard "VALU writes a VGPR -> DPP reads it: 2
+    // wait states" is not tracked through inline assembly: the s_nop in front of the first element covers the
+    // registers written just before the group; inside the group every element reads a register of its own.
+    template <int K, int N> QPX_DEV void row_rank1(double (&a)[N], double m) const
+    {
+        static_assert(K >= 0 && K < 16, "row of 16 lanes");
+        bool first = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j == K) continue;
+#define QPX_FMAC_DPP(KK)                                                                                          \
+    if constexpr (K == KK) {                                                                                      \
+        if (first)                                                                                                \
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:" #KK " row_mask:0xf bank_mask:0xf" \
+                         : "+v"(a[j])                                                                             \
+                         : "v"(m));                                                                               \
+        else                                                                                                      \
+            asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:" #KK " row_mask:0xf bank_mask:0xf"              \
+                         : "+v"(a[j])                                                                             \
+                         : "v"(m));                                                                               \
+    }
+            QPX_FMAC_DPP(0) QPX_FMAC_DPP(1) QPX_FMAC_DPP(2) QPX_FMAC_DPP(3) QPX_FMAC_DPP(4) QPX_FMAC_DPP(5)
+            QPX_FMAC_DPP(6) QPX_FMAC_DPP(7) QPX_FMAC_DPP(8) QPX_FMAC_DPP(9) QPX_FMAC_DPP(10) QPX_FMAC_DPP(11)
+            QPX_FMAC_DPP(12) QPX_FMAC_DPP(13) QPX_FMAC_DPP(14) QPX_FMAC_DPP(15)
+#undef QPX_FMAC_DPP
+            first = false;
+        }
+    }
+
     // c += A B on the matrix core, A 16x4, B 4x16, one wave (v_mfma_f64_16x16x4_f64).  Lane l gives
     // a = A[l & 15][l >> 4], b = B[l >> 4][l & 15] and holds c[r] = C[(l >> 4) + 4 r][l & 15].
     QPX_DEV void mfma16x16x4(double a, double b, double (&c)[4]) const

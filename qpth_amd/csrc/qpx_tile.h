@@ -58,6 +58,27 @@ static __device__ unsigned long long qpx_panel_prof[8];   // one copy per transl
 
 namespace qpx {
 
+#ifndef QPX_TILE_PANEL4
+// row stride of the panel's X rows (17 mod 32 doubles) and size of the region the mat-vec partials share with the
+// operand tiles of the factorisation
+QPX_LAYOUT_HD constexpr int tile_xs(int nbl) { return ((16 * nbl - 17 + 31) / 32) * 32 + 17; }
+QPX_LAYOUT_HD constexpr int tile_union(int nbl, int nw)
+{
+    const int npos = (nbl + nw - 1) / nw, a = nw * nbl * 64 + nw * 16 * npos * 17, b = nbl * 256;
+    return a > b ? a : b;
+}
+QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nw)
+{
+    return (size_t)16 * tile_xs(nbl) + 2 * 16 * 18 + 2 + tile_union(nbl, nw) + 16 * (size_t)nbl;
+}
+#else
+QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nw)
+{
+    const size_t mp = 16 * (size_t)nbl, npos = (size_t)(nbl + nw - 1) / nw;
+    return 8 * mp + 32 + (size_t)nw * nbl * 64 + (size_t)nw * 16 * npos * 17 + mp;
+}
+#endif
+
 template <int NBL, int NW> struct TileMat {
     using T = double;
     static constexpr int NPOS = (NBL + NW - 1) / NW, NT = 64 * NW, MP = 16 * NBL;
@@ -101,8 +122,19 @@ template <int NBL, int NW> struct TileMat {
         QPX_DEV int row(int p) const { return NBL - 1 - p * NW - ((p & 1) ? NW - 1 - w : w); }   // = rowof(p, w)
     };
     struct Regs { T e[NSLOT][4]; };
+#ifdef QPX_TILE_PANEL4
     // scratch: X (2 x 4 x MP) | S (2 x 16) | part (NW x NBL x 64) | red (NW x NROW x 17) | yrow (MP)
     static constexpr int kX = 0, kS = 8 * MP, kPart = kS + 32, kRed = kPart + NW * NBL * 64, kRow = kRed + NW * NROW * 17;
+#else
+    // scratch: X (16 x XS: the 16 old rows of a panel) | S, W (16 x SS: pivot block, its inverse factor) | flag |
+    // { part (NW x NBL x 64) | red (NW x NROW x 17) } or, during a factorisation, BT (NBL x 256: the operand
+    // tiles) | yrow (MP).  XS = 17 mod 32 and SS = 18 keep both the row-wise and the transposed accesses
+    // (lane stride XS resp. SS doubles) on distinct LDS banks.
+    static constexpr int XS = tile_xs(NBL), SS = 18;
+    static constexpr int kX = 0, kS = 16 * XS, kW = kS + 16 * SS, kFlag = kW + 16 * SS, kPart = kFlag + 2;
+    static constexpr int kRed = kPart + NW * NBL * 64, kBT = kPart;
+    static constexpr int kRow = kPart + tile_union(NBL, NW);
+#endif
     QPX_LAYOUT_HD static size_t scratch_elems() { return (size_t)kRow + MP; }
     static QPX_DEV void sync(const Block& blk)
     {
@@ -222,6 +254,7 @@ template <int NBL, int NW> struct TileMat {
         sync(blk);
     }
 
+#ifdef QPX_TILE_PANEL4
     // ---- one panel of ldl_inv: rows/columns k0 .. k0+3, k0 = 16 Ip + 4 SP.  gm[k] = (g == k) as 0/1.
     template <int SP>
     static QPX_DEV int panel(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, const T (&gm)[4],
@@ -388,6 +421,199 @@ template <int NBL, int NW> struct TileMat {
         return ldl_inv_signed(blk, p, E, scr, rd, m, MP, MP) == 0;
     }
 
+#else
+    // ---- ldl_inv BLOCKED BY SIXTEEN COLUMNS (one tile column per panel, two barriers per panel).
+    //
+    // Panel Ip = rows/columns 16 Ip .. 16 Ip + 15, pivot block P = E(Ip, Ip) = L~_pp D L~_pp^T, W_pp = L~_pp^-1:
+    //   publish   X_J (16 x 16, J = 0 .. NBL-1, J != Ip) = the panel's sixteen "old" rows: the W~ entries E(Ip, J) left
+    //             of the panel (from the wave that owns tile row Ip), the panel's columns read down the matrix,
+    //             E(J, Ip)^T, right of it (from the owners of those tiles, which then restart them from zero).
+    //   factor    the owner of tile row Ip moves P to "lane c = row c, sixteen registers" (through LDS, inside the
+    //             wave) and eliminates it there: per pivot one v_rcp_f64_dpp + Newton, and ONE v_fmac_f64_dpp per
+    //             register -- the pivot row arrives through the DPP row broadcast, nothing is published, no
+    //             barrier.  The same rank-1 update builds W~ in place of the eliminated columns (as everywhere in
+    //             this file).  It overlaps with the other waves' publish.              -- barrier A --
+    //   operands  b_J = W_pp X_J on the matrix core (4 MFMAs per J, the J dealt over the waves; b_Ip = W_pp), written
+    //             to LDS in the accumulator layout.                                   -- barrier B --
+    //   update    E(Ip, J) = b_J (the panel's own rows are final);  E(I, J) += (-D^-1 b_I)^T b_J for I > Ip, J <= I:
+    //             register r of b_J is the B operand of k-slice r as it is, and register r of b_I times -1/d is the
+    //             A operand (the accumulator layout indexes both by (row g + 4 r, column c)).
+    // Per sixteen columns: 2 barriers (four-column panels: 4), ~30 + 16 x 27 (one wave) vector instructions per
+    // wave around the MFMAs (four-column panels: 4 x 230 in every wave).
+    template <int K> static QPX_DEV void pivot16(const Block& blk, const Pos& p, T (&a)[16], T* rd, int k0, bool& bad)
+    {
+        const T dk = blk.template row_bcast<K>(a[K]);
+        const T r = rcp_(dk);
+        bad = bad || !(dk > T(0) && dk < T(1e300));        // NaN fails d > 0, +inf fails d < big
+        if (p.lane == K) rd[k0 + K] = r;
+        const T nl = p.c > K ? -(a[K] * r) : T(0);         // -l~ for the rows below the pivot, 0 for the others
+        if constexpr (K < 15) blk.template row_rank1<K>(a, nl);
+        a[K] = nl;                                         // assigned, not updated (see qpx_grid.h); 0 on and above the diagonal
+    }
+
+    static QPX_DEV bool panel16(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, long long (&pacc)[8])
+    {
+        QPX_PP(5)
+        T* X = scr + kX;
+        T* S = scr + kS;
+        T* W = scr + kW;
+        T* BT = scr + kBT;
+        T* flag = scr + kFlag;
+        const int k0 = 16 * Ip;
+        bool mine = false;
+        // -- publish
+#pragma unroll
+        for (int pp = 0; pp < NPOS; ++pp) {
+            const int I = p.row(pp);
+            if (I < Ip) continue;
+            if (I == Ip) mine = true;
+#pragma unroll
+            for (int J = 0; J < psize(pp); ++J) {
+                if (J > Ip) continue;
+                if (I == Ip) {
+                    if (J < Ip) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[(p.g + 4 * r) * XS + 16 * J + p.c] = E.e[slot(pp, J)][r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) S[(p.g + 4 * r) * SS + p.c] = E.e[slot(pp, J)][r];
+                    }
+                } else if (J == Ip) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        X[p.c * XS + 16 * I + p.g + 4 * r] = E.e[slot(pp, J)][r];
+                        E.e[slot(pp, J)][r] = T(0);
+                    }
+                }
+            }
+        }
+        QPX_PP(0)
+        // -- the pivot block, by the wave that owns it
+        if (mine) {
+            blk.wave_sync();
+            T a[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = S[p.c * SS + j];
+            bool bad = false;
+            pivot16<0>(blk, p, a, rd, k0, bad);
+            pivot16<1>(blk, p, a, rd, k0, bad);
+            pivot16<2>(blk, p, a, rd, k0, bad);
+            pivot16<3>(blk, p, a, rd, k0, bad);
+            pivot16<4>(blk, p, a, rd, k0, bad);
+            pivot16<5>(blk, p, a, rd, k0, bad);
+            pivot16<6>(blk, p, a, rd, k0, bad);
+            pivot16<7>(blk, p, a, rd, k0, bad);
+            pivot16<8>(blk, p, a, rd, k0, bad);
+            pivot16<9>(blk, p, a, rd, k0, bad);
+            pivot16<10>(blk, p, a, rd, k0, bad);
+            pivot16<11>(blk, p, a, rd, k0, bad);
+            pivot16<12>(blk, p, a, rd, k0, bad);
+            pivot16<13>(blk, p, a, rd, k0, bad);
+            pivot16<14>(blk, p, a, rd, k0, bad);
+            pivot16<15>(blk, p, a, rd, k0, bad);
+            if (p.g == 0) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) W[p.c * SS + j] = a[j];
+            }
+            if (p.lane == 0) flag[0] = bad ? T(1) : T(0);
+        }
+        QPX_PP(1)
+        sync(blk);
+        QPX_PP(2)
+        if (flag[0] != T(0)) return false;
+        // -- operand tiles: b_J = (I + W_strict) X_J
+        {
+            T wa[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wa[s] = W[p.c * SS + p.g + 4 * s];
+#pragma unroll
+            for (int jj = 0; jj < (NBL + NW - 1) / NW; ++jj) {
+                const int J = p.w + jj * NW;
+                if (J >= NBL) continue;
+                T acc[4];
+                if (J == Ip) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = W[(p.g + 4 * r) * SS + p.c] + ((p.g + 4 * r == p.c) ? T(1) : T(0));
+                } else {
+                    T bx[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[s] = bx[s] = X[(p.g + 4 * s) * XS + 16 * J + p.c];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) blk.mfma16x16x4(wa[s], bx[s], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) BT[J * 256 + r * 64 + p.lane] = acc[r];
+            }
+        }
+        QPX_PP(3)
+        sync(blk);
+        QPX_PP(4)
+        // -- update
+        T aop[NPOS][4];
+        {
+            T nrd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nrd[r] = -rd[k0 + p.g + 4 * r];
+#pragma unroll
+            for (int pp = 0; pp < NPOS; ++pp) {
+                const int I = p.row(pp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) aop[pp][r] = T(0);
+                if (I <= Ip) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) aop[pp][r] = BT[I * 256 + r * 64 + p.lane] * nrd[r];
+            }
+        }
+#pragma unroll
+        for (int J = 0; J < NBL; ++J) {
+            bool need = false;
+#pragma unroll
+            for (int pp = 0; pp < NPOS; ++pp) {
+                if (J >= psize(pp)) continue;
+                const int I = p.row(pp);
+                need = need || (I == Ip && J <= Ip) || (I > Ip && J <= I);
+            }
+            if (!need) continue;
+            T bj[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bj[r] = BT[J * 256 + r * 64 + p.lane];
+#pragma unroll
+            for (int pp = 0; pp < NPOS; ++pp) {
+                if (J >= psize(pp)) continue;
+                const int I = p.row(pp);
+                if (I == Ip && J <= Ip) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) E.e[slot(pp, J)][r] = bj[r];
+                } else if (I > Ip && J <= I) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) blk.mfma16x16x4(aop[pp][s], bj[s], E.e[slot(pp, J)]);
+                }
+            }
+        }
+        return true;
+    }
+
+    // E: T (SPD, order m, padded with the identity) -> strictly lower: W~ = L~^-1, rd[k] = 1/d_k; false: a pivot
+    // broke down (uniform)
+    static QPX_DEV bool ldl_inv(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int m)
+    {
+        bool ok = true;
+        long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef QPX_PANEL_PROF
+        pacc[7] = clock64();
+#endif
+#pragma unroll 1
+        for (int Ip = 0; Ip < NBL && ok && 16 * Ip < m; ++Ip) ok = panel16(blk, p, E, scr, rd, Ip, pacc);
+#ifdef QPX_PANEL_PROF
+        if (p.tid == 0) {
+            for (int i = 0; i < 6; ++i) atomicAdd(&qpx_panel_prof[i], (unsigned long long)pacc[i]);
+            atomicAdd(&qpx_panel_prof[6], 1ull);
+        }
+#endif
+        sync(blk);
+        return ok;
+    }
+#endif
     // vout = -T^-1 vin = -W~^T D^-1 W~ vin (W~ unit lower in E, strictly lower part stored)
     static QPX_DEV void solve_neg(const Block& blk, const Pos& p, const Regs& E, const T* rd, int m, const T* vin,
                                   T* vout, T* tmp, T* scr)
@@ -448,14 +674,12 @@ template <int NBL, int NW> struct TileMat {
 
 QPX_LAYOUT_HD size_t lds_elems_ipm_tile(int nbl, int nw, int n, int q)
 {
-    const size_t mp = 16 * (size_t)nbl, npos = (size_t)(nbl + nw - 1) / nw;
-    return lds_elems_ipm_loop(mp, 8 * mp + 32 + (size_t)nw * nbl * 64 + (size_t)nw * 16 * npos * 17 + mp, n, q);
+    return lds_elems_ipm_loop(16 * (size_t)nbl, tile_scratch_elems(nbl, nw), n, q);
 }
 
 QPX_LAYOUT_HD size_t lds_elems_kkt_tile(int nbl, int nw, int n, int q)
 {
-    const size_t mp = 16 * (size_t)nbl, npos = (size_t)(nbl + nw - 1) / nw;
-    return lds_elems_kkt_mat(mp, 8 * mp + 32 + (size_t)nw * nbl * 64 + (size_t)nw * 16 * npos * 17 + mp, n, q);
+    return lds_elems_kkt_mat(16 * (size_t)nbl, tile_scratch_elems(nbl, nw), n, q);
 }
 
 template <int NBL, int NW, bool kBackward>

@@ -16,7 +16,11 @@ import problems  # noqa: E402
 from qpth_amd import _lib  # noqa: E402
 from qpth_amd.kkt import KKTFactors  # noqa: E402
 
-NAMES = ["publish", "barrier", "S read + 4x4 + masks", "operands (LDS + fma)", "assign + mfma issue", "entry (mfma drain)"]
+# sixteen-column panels (the shipped build); the four-column form (-DQPX_TILE_PANEL4) cuts at other places
+NAMES16 = ["publish (X, S)", "pivot block (when wave 0 owns it)", "barrier A (waits for the pivot block)", "operand tiles (LDS + 4 mfma per J)", "barrier B", "update of the previous panel (LDS + mfma)"]
+NAMES4 = ["publish", "barrier", "S read + 4x4 + masks", "operands (LDS + fma)", "assign + mfma issue", "entry (mfma drain)"]
+PANEL = int(os.environ.get("QPX_PANEL_COLS", "16"))
+NAMES = NAMES16 if PANEL == 16 else NAMES4
 
 
 def main():
@@ -35,7 +39,7 @@ def main():
         lib.dll.qpx_panel_prof_read(out)
     c = np.array(list(out), dtype=np.float64)
     nfac = c[6]
-    npan = (m + 3) // 4
+    npan = (m + PANEL - 1) // PANEL
     print("B=%d n=%d m=%d q=%d variant=%s: %d factorisations, %d panels each; ticks per factorisation %.0f" % (
         B, n, m, q, os.environ.get("QPX_VARIANT", "0"), nfac, npan, c[:6].sum() / nfac))
     for i, nm in enumerate(NAMES):

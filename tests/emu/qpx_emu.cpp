@@ -70,6 +70,8 @@ template <class Body> static void run_block(int nt, const Body& body)
     sh.xchg = xchg.data();
     std::vector<unsigned long long> xchg2(nt, 0);
     sh.xchg2 = xchg2.data();
+    std::vector<double> xv((size_t)nt * 16, 0.0);
+    sh.xv = xv.data();
     std::vector<ThreadCtx<Body>> ctx(nt);
     std::vector<pthread_t> th(nt);
     pthread_attr_t attr;

@@ -28,6 +28,7 @@ struct EmuShared {
     pthread_barrier_t* wave_bar;   // one per wave
     unsigned long long* xchg;      // one 8-byte exchange slot per thread
     unsigned long long* xchg2;     // a second one (the B operand of the emulated MFMA)
+    double* xv;                    // 16 doubles per thread (row_rank1: a whole register row in one round)
 };
 
 struct Block {
@@ -62,6 +63,19 @@ struct Block {
     int bcast(int v, int src) const { return exchange(v, src); }
     template <int MASK> double xor16(double v) const { return exchange(v, lane() ^ MASK); }
     template <int MASK> float xor16(float v) const { return exchange(v, lane() ^ MASK); }
+
+    // DPP row_newbcast and the fused multiply-add through it (see the HIP header)
+    template <int K> double row_bcast(double v) const { return exchange(v, (lane() & ~15) | K); }
+    template <int K, int N> void row_rank1(double (&a)[N], double m) const
+    {
+        static_assert(N <= 16, "xv holds 16 values per thread");
+        for (int j = 0; j < N; ++j) sh->xv[(size_t)tid * 16 + j] = a[j];
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        const double* src = sh->xv + (size_t)((tid & ~15) | K) * 16;
+        for (int j = 0; j < N; ++j)
+            if (j != K) a[j] = std::fma(src[j], m, a[j]);
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+    }
 
     // c += A B, A 16x4, B 4x16 (see the HIP header for the lane mapping); products are summed in
     // k order with fused multiply-adds -- the hardware's internal order is not documented, so GPU
