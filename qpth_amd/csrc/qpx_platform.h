@@ -96,7 +96,7 @@ struct Block {
     {
         return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true);
     }
-    // a[j] += (a[j] of lane K of this row of 16) * m for every j != K: ONE instruction per element
+    // a[j] += (a[j] of lane K of this row of 16) * m for every j: ONE instruction per element
     // (v_fmac_f64_dpp, src0 through the row broadcast).  The compiler does not form it from update_dpp + fma
     // (it keeps a v_mov_b64_dpp per element), hence the assembly.  Hazard "VALU writes a VGPR -> DPP reads it: 2
     // wait states" is not tracked through inline assembly: the s_nop in front of the first element covers the
@@ -107,7 +107,6 @@ struct Block {
         bool first = true;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            if (j == K) continue;
 #define QPX_FMAC_DPP(KK)                                                                                          \
     if constexpr (K == KK) {                                                                                      \
         if (first)                                                                                                \
@@ -125,6 +124,31 @@ struct Block {
 #undef QPX_FMAC_DPP
             first = false;
         }
+    }
+
+    // the value lane (GK, c) holds, in every lane (g, c), g = 0 .. 3 (rows of 16 lanes): gfx950's two lane-swap
+    // instructions.  v_permlane32_swap(x, y) exchanges rows 2, 3 of x with rows 0, 1 of y; v_permlane16_swap(x, y)
+    // exchanges the odd rows of x with the even rows of y -- applied to two copies of the value they leave one
+    // register with the lower (even) rows everywhere and one with the upper (odd) rows.  8 instructions per
+    // double, no LDS.  (-DQPX_GRP_BCAST_BPERMUTE: the same through ds_bpermute, kept for A/B.)
+    template <int GK> QPX_DEV double grp_bcast(double v) const
+    {
+        static_assert(GK >= 0 && GK < 4, "four rows of 16 lanes");
+#ifdef QPX_GRP_BCAST_BPERMUTE
+        return __shfl(v, GK * 16 + (lane() & 15), kWave);
+#else
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const long long b = __double_as_longlong(v);
+        unsigned w[2] = {(unsigned)(b & 0xffffffffll), (unsigned)(b >> 32)};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u2 s32 = __builtin_amdgcn_permlane32_swap(w[h], w[h], false, false);
+            const unsigned x = GK < 2 ? s32.x : s32.y;
+            const u2 s16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+            w[h] = (GK & 1) ? s16.y : s16.x;
+        }
+        return __longlong_as_double(((long long)w[1] << 32) | w[0]);
+#endif
     }
 
     // c += A B on the matrix core, A 16x4, B 4x16, one wave (v_mfma_f64_16x16x4_f64).  Lane l gives

@@ -428,27 +428,41 @@ template <int NBL, int NW> struct TileMat {
     //   publish   X_J (16 x 16, J = 0 .. NBL-1, J != Ip) = the panel's sixteen "old" rows: the W~ entries E(Ip, J) left
     //             of the panel (from the wave that owns tile row Ip), the panel's columns read down the matrix,
     //             E(J, Ip)^T, right of it (from the owners of those tiles, which then restart them from zero).
-    //   factor    the owner of tile row Ip moves P to "lane c = row c, sixteen registers" (through LDS, inside the
-    //             wave) and eliminates it there: per pivot one v_rcp_f64_dpp + Newton, and ONE v_fmac_f64_dpp per
-    //             register -- the pivot row arrives through the DPP row broadcast, nothing is published, no
-    //             barrier.  The same rank-1 update builds W~ in place of the eliminated columns (as everywhere in
-    //             this file).  It overlaps with the other waves' publish.              -- barrier A --
+    //   factor    the owner of tile row Ip moves P to "lane (g, c) = row c, columns 4 g .. 4 g + 3" (through LDS, inside
+    //             the wave) and eliminates it there: per pivot one v_rcp_f64_dpp + Newton, the multipliers copied to
+    //             the four lane groups by lane swaps, and ONE v_fmac_f64_dpp per register -- the pivot row arrives
+    //             through the DPP row broadcast; nothing is published, no barrier.  The same rank-1 update builds W~
+    //             in place of the eliminated columns (as everywhere in this file).  It overlaps with the other
+    //             waves' publish.                                                       -- barrier A --
     //   operands  b_J = W_pp X_J on the matrix core (4 MFMAs per J, the J dealt over the waves; b_Ip = W_pp), written
     //             to LDS in the accumulator layout.                                   -- barrier B --
     //   update    E(Ip, J) = b_J (the panel's own rows are final);  E(I, J) += (-D^-1 b_I)^T b_J for I > Ip, J <= I:
     //             register r of b_J is the B operand of k-slice r as it is, and register r of b_I times -1/d is the
     //             A operand (the accumulator layout indexes both by (row g + 4 r, column c)).
-    // Per sixteen columns: 2 barriers (four-column panels: 4), ~30 + 16 x 27 (one wave) vector instructions per
+    // Per sixteen columns: 2 barriers (four-column panels: 4), ~30 + 16 x 25 (one wave) vector instructions per
     // wave around the MFMAs (four-column panels: 4 x 230 in every wave).
-    template <int K> static QPX_DEV void pivot16(const Block& blk, const Pos& p, T (&a)[16], T* rd, int k0, bool& bad)
+    // Pivot K of the 16 x 16 pivot block held as lane (g, c) = row c, columns 4 g .. 4 g + 3 (four registers) plus,
+    // in every group, the row's own diagonal entry dg (updated by dg -= l~^2 d, which needs nothing from other
+    // lanes): the pivot d_K is then lane K's dg in every group, so its reciprocal (the long chain: estimate + two
+    // Newton steps) runs beside the lane swaps that copy column K from its group K / 4 to the other three.  Every
+    // lane then updates its four columns with the pivot row from lane K of its own row of 16 lanes.
+    template <int K>
+    static QPX_DEV void pivot16(const Block& blk, const Pos& p, T (&a)[4], T& dg, T& myr, bool& bad)
     {
-        const T dk = blk.template row_bcast<K>(a[K]);
+        constexpr int GK = K / 4, KK = K % 4;
+        const T dk = blk.template row_bcast<K>(dg);
         const T r = rcp_(dk);
-        bad = bad || !(dk > T(0) && dk < T(1e300));        // NaN fails d > 0, +inf fails d < big
-        if (p.lane == K) rd[k0 + K] = r;
-        const T nl = p.c > K ? -(a[K] * r) : T(0);         // -l~ for the rows below the pivot, 0 for the others
-        if constexpr (K < 15) blk.template row_rank1<K>(a, nl);
-        a[K] = nl;                                         // assigned, not updated (see qpx_grid.h); 0 on and above the diagonal
+        bad = bad || !(dk > T(0) && dk < T(1e300));              // NaN fails d > 0, +inf fails d < big
+        myr = p.lane == K ? r : myr;
+        if constexpr (K < 15) {
+            const T v = blk.template grp_bcast<GK>(p.c > K ? a[KK] : T(0));   // column K below the pivot, 0 above
+            const T nl = -(v * r);                               // -l~
+            blk.template row_rank1<K>(a, nl);
+            a[KK] = p.g == GK ? nl : a[KK];                      // column K: assigned (see qpx_grid.h); 0 on and above the diagonal
+            dg = fma_(nl, v, dg);
+        } else {
+            a[KK] = p.g == GK ? T(0) : a[KK];
+        }
     }
 
     static QPX_DEV bool panel16(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, long long (&pacc)[8])
@@ -491,30 +505,30 @@ template <int NBL, int NW> struct TileMat {
         // -- the pivot block, by the wave that owns it
         if (mine) {
             blk.wave_sync();
-            T a[16];
+            T a[4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = S[p.c * SS + j];
+            for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
+            T dg = S[p.c * SS + p.c], myr = T(0);
             bool bad = false;
-            pivot16<0>(blk, p, a, rd, k0, bad);
-            pivot16<1>(blk, p, a, rd, k0, bad);
-            pivot16<2>(blk, p, a, rd, k0, bad);
-            pivot16<3>(blk, p, a, rd, k0, bad);
-            pivot16<4>(blk, p, a, rd, k0, bad);
-            pivot16<5>(blk, p, a, rd, k0, bad);
-            pivot16<6>(blk, p, a, rd, k0, bad);
-            pivot16<7>(blk, p, a, rd, k0, bad);
-            pivot16<8>(blk, p, a, rd, k0, bad);
-            pivot16<9>(blk, p, a, rd, k0, bad);
-            pivot16<10>(blk, p, a, rd, k0, bad);
-            pivot16<11>(blk, p, a, rd, k0, bad);
-            pivot16<12>(blk, p, a, rd, k0, bad);
-            pivot16<13>(blk, p, a, rd, k0, bad);
-            pivot16<14>(blk, p, a, rd, k0, bad);
-            pivot16<15>(blk, p, a, rd, k0, bad);
-            if (p.g == 0) {
+            pivot16<0>(blk, p, a, dg, myr, bad);
+            pivot16<1>(blk, p, a, dg, myr, bad);
+            pivot16<2>(blk, p, a, dg, myr, bad);
+            pivot16<3>(blk, p, a, dg, myr, bad);
+            pivot16<4>(blk, p, a, dg, myr, bad);
+            pivot16<5>(blk, p, a, dg, myr, bad);
+            pivot16<6>(blk, p, a, dg, myr, bad);
+            pivot16<7>(blk, p, a, dg, myr, bad);
+            pivot16<8>(blk, p, a, dg, myr, bad);
+            pivot16<9>(blk, p, a, dg, myr, bad);
+            pivot16<10>(blk, p, a, dg, myr, bad);
+            pivot16<11>(blk, p, a, dg, myr, bad);
+            pivot16<12>(blk, p, a, dg, myr, bad);
+            pivot16<13>(blk, p, a, dg, myr, bad);
+            pivot16<14>(blk, p, a, dg, myr, bad);
+            pivot16<15>(blk, p, a, dg, myr, bad);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) W[p.c * SS + j] = a[j];
-            }
+            for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = a[j];
+            if (p.lane < 16) rd[k0 + p.lane] = myr;
             if (p.lane == 0) flag[0] = bad ? T(1) : T(0);
         }
         QPX_PP(1)

@@ -72,10 +72,10 @@ struct Block {
         for (int j = 0; j < N; ++j) sh->xv[(size_t)tid * 16 + j] = a[j];
         pthread_barrier_wait(&sh->wave_bar[wave()]);
         const double* src = sh->xv + (size_t)((tid & ~15) | K) * 16;
-        for (int j = 0; j < N; ++j)
-            if (j != K) a[j] = std::fma(src[j], m, a[j]);
+        for (int j = 0; j < N; ++j) a[j] = std::fma(src[j], m, a[j]);
         pthread_barrier_wait(&sh->wave_bar[wave()]);
     }
+    template <int GK> double grp_bcast(double v) const { return exchange(v, GK * 16 + (lane() & 15)); }
 
     // c += A B, A 16x4, B 4x16 (see the HIP header for the lane mapping); products are summed in
     // k order with fused multiply-adds -- the hardware's internal order is not documented, so GPU
