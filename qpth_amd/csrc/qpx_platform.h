@@ -151,6 +151,9 @@ struct Block {
 #endif
     }
 
+    // true in every lane iff `v` is true in some lane of the wave
+    QPX_DEV bool any(bool v) const { return __builtin_amdgcn_ballot_w64(v) != 0ull; }
+
     // c += A B on the matrix core, A 16x4, B 4x16, one wave (v_mfma_f64_16x16x4_f64).  Lane l gives
     // a = A[l & 15][l >> 4], b = B[l >> 4][l & 15] and holds c[r] = C[(l >> 4) + 4 r][l & 15].
     QPX_DEV void mfma16x16x4(double a, double b, double (&c)[4]) const

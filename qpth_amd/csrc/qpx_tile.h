@@ -427,7 +427,7 @@ template <int NBL, int NW> struct TileMat {
     // Panel Ip = rows/columns 16 Ip .. 16 Ip + 15, pivot block P = E(Ip, Ip) = L~_pp D L~_pp^T, W_pp = L~_pp^-1:
     //   publish   X_J (16 x 16, J = 0 .. NBL-1, J != Ip) = the panel's sixteen "old" rows: the W~ entries E(Ip, J) left
     //             of the panel (from the wave that owns tile row Ip), the panel's columns read down the matrix,
-    //             E(J, Ip)^T, right of it (from the owners of those tiles, which then restart them from zero).
+    //             E(J, Ip)^T, right of it (from the owners of those tiles; the update restarts them from zero).
     //   factor    the owner of tile row Ip moves P to "lane (g, c) = row c, columns 4 g .. 4 g + 3" (through LDS, inside
     //             the wave) and eliminates it there: per pivot one v_rcp_f64_dpp + Newton, the multipliers copied to
     //             the four lane groups by lane swaps, and ONE v_fmac_f64_dpp per register -- the pivot row arrives
@@ -447,13 +447,12 @@ template <int NBL, int NW> struct TileMat {
     // Newton steps) runs beside the lane swaps that copy column K from its group K / 4 to the other three.  Every
     // lane then updates its four columns with the pivot row from lane K of its own row of 16 lanes.
     template <int K>
-    static QPX_DEV void pivot16(const Block& blk, const Pos& p, T (&a)[4], T& dg, T& myr, bool& bad)
+    static QPX_DEV void pivot16(const Block& blk, const Pos& p, T (&a)[4], T& dg, T& myr)
     {
         constexpr int GK = K / 4, KK = K % 4;
         const T dk = blk.template row_bcast<K>(dg);
         const T r = rcp_(dk);
-        bad = bad || !(dk > T(0) && dk < T(1e300));              // NaN fails d > 0, +inf fails d < big
-        myr = p.lane == K ? r : myr;
+        myr = p.lane == K ? r : myr;                             // (the pivots are checked together, after the block)
         if constexpr (K < 15) {
             const T v = blk.template grp_bcast<GK>(p.c > K ? a[KK] : T(0));   // column K below the pivot, 0 above
             const T nl = -(v * r);                               // -l~
@@ -494,10 +493,7 @@ template <int NBL, int NW> struct TileMat {
                     }
                 } else if (J == Ip) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        X[p.c * XS + 16 * I + p.g + 4 * r] = E.e[slot(pp, J)][r];
-                        E.e[slot(pp, J)][r] = T(0);
-                    }
+                    for (int r = 0; r < 4; ++r) X[p.c * XS + 16 * I + p.g + 4 * r] = E.e[slot(pp, J)][r];
                 }
             }
         }
@@ -508,33 +504,37 @@ template <int NBL, int NW> struct TileMat {
             T a[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
-            T dg = S[p.c * SS + p.c], myr = T(0);
-            bool bad = false;
-            pivot16<0>(blk, p, a, dg, myr, bad);
-            pivot16<1>(blk, p, a, dg, myr, bad);
-            pivot16<2>(blk, p, a, dg, myr, bad);
-            pivot16<3>(blk, p, a, dg, myr, bad);
-            pivot16<4>(blk, p, a, dg, myr, bad);
-            pivot16<5>(blk, p, a, dg, myr, bad);
-            pivot16<6>(blk, p, a, dg, myr, bad);
-            pivot16<7>(blk, p, a, dg, myr, bad);
-            pivot16<8>(blk, p, a, dg, myr, bad);
-            pivot16<9>(blk, p, a, dg, myr, bad);
-            pivot16<10>(blk, p, a, dg, myr, bad);
-            pivot16<11>(blk, p, a, dg, myr, bad);
-            pivot16<12>(blk, p, a, dg, myr, bad);
-            pivot16<13>(blk, p, a, dg, myr, bad);
-            pivot16<14>(blk, p, a, dg, myr, bad);
-            pivot16<15>(blk, p, a, dg, myr, bad);
+            T dg = S[p.c * SS + p.c], myr = T(1);
+            pivot16<0>(blk, p, a, dg, myr);
+            pivot16<1>(blk, p, a, dg, myr);
+            pivot16<2>(blk, p, a, dg, myr);
+            pivot16<3>(blk, p, a, dg, myr);
+            pivot16<4>(blk, p, a, dg, myr);
+            pivot16<5>(blk, p, a, dg, myr);
+            pivot16<6>(blk, p, a, dg, myr);
+            pivot16<7>(blk, p, a, dg, myr);
+            pivot16<8>(blk, p, a, dg, myr);
+            pivot16<9>(blk, p, a, dg, myr);
+            pivot16<10>(blk, p, a, dg, myr);
+            pivot16<11>(blk, p, a, dg, myr);
+            pivot16<12>(blk, p, a, dg, myr);
+            pivot16<13>(blk, p, a, dg, myr);
+            pivot16<14>(blk, p, a, dg, myr);
+            pivot16<15>(blk, p, a, dg, myr);
 #pragma unroll
             for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = a[j];
             if (p.lane < 16) rd[k0 + p.lane] = myr;
+            // a pivot that is not positive and finite leaves a reciprocal that is not (negative, NaN from inf - inf or
+            // 0 * inf further down, 0 or inf); nothing above traps, so one test of the sixteen reciprocals replaces
+            // two compares in every pivot's chain
+            const bool bad = blk.any(!(myr > T(0) && myr < T(1e300)));
             if (p.lane == 0) flag[0] = bad ? T(1) : T(0);
         }
         QPX_PP(1)
         sync(blk);
         QPX_PP(2)
-        if (flag[0] != T(0)) return false;
+        const T zr = flag[0];                 // 0 from here on
+        if (zr != T(0)) return false;
         // -- operand tiles: b_J = (I + W_strict) X_J
         {
             T wa[4];
@@ -578,6 +578,18 @@ template <int NBL, int NW> struct TileMat {
                 for (int r = 0; r < 4; ++r) aop[pp][r] = BT[I * 256 + r * 64 + p.lane] * nrd[r];
             }
         }
+        // the panel's own rows are final: W~ rows left of the panel, L~_pp^-1 inside it -- read straight into the tile
+        // registers (an assignment from registers another path also uses costs round-trip copies of the tile)
+#pragma unroll
+        for (int pp = 0; pp < NPOS; ++pp) {
+            if (p.row(pp) != Ip) continue;
+#pragma unroll
+            for (int J = 0; J < psize(pp); ++J) {
+                if (J > Ip) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) E.e[slot(pp, J)][r] = BT[J * 256 + r * 64 + p.lane];
+            }
+        }
 #pragma unroll
         for (int J = 0; J < NBL; ++J) {
             bool need = false;
@@ -585,20 +597,22 @@ template <int NBL, int NW> struct TileMat {
             for (int pp = 0; pp < NPOS; ++pp) {
                 if (J >= psize(pp)) continue;
                 const int I = p.row(pp);
-                need = need || (I == Ip && J <= Ip) || (I > Ip && J <= I);
+                need = need || (I > Ip && J <= I);
             }
             if (!need) continue;
             T bj[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) bj[r] = BT[J * 256 + r * 64 + p.lane];
+            // the panel's own columns restart from zero (their old values went into X): multiplied by a factor that is
+            // 0 there and 1 elsewhere, outside every branch
+            const T keep = J == Ip ? zr : T(1);
 #pragma unroll
             for (int pp = 0; pp < NPOS; ++pp) {
                 if (J >= psize(pp)) continue;
                 const int I = p.row(pp);
-                if (I == Ip && J <= Ip) {
+                if (I > Ip && J <= I) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) E.e[slot(pp, J)][r] = bj[r];
-                } else if (I > Ip && J <= I) {
+                    for (int r = 0; r < 4; ++r) E.e[slot(pp, J)][r] *= keep;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) blk.mfma16x16x4(aop[pp][s], bj[s], E.e[slot(pp, J)]);
                 }

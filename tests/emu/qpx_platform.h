@@ -77,6 +77,16 @@ struct Block {
     }
     template <int GK> double grp_bcast(double v) const { return exchange(v, GK * 16 + (lane() & 15)); }
 
+    bool any(bool v) const
+    {
+        sh->xchg[tid] = v ? 1ull : 0ull;
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        unsigned long long r = 0;
+        for (int l = 0; l < kWave; ++l) r |= sh->xchg[(tid & ~(kWave - 1)) | l];
+        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        return r != 0;
+    }
+
     // c += A B, A 16x4, B 4x16 (see the HIP header for the lane mapping); products are summed in
     // k order with fused multiply-adds -- the hardware's internal order is not documented, so GPU
     // and emulation agree to rounding, not bit for bit, once this is used
