@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "qpx_kernels.h"
+#include "qpx_tile.h"
 
 using namespace qpx;
 
@@ -187,6 +188,67 @@ template <int NACC> __global__ __launch_bounds__(64) void k_vfma_tile(double* ou
     if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (4.0 * NACC * reps);
 }
 
+// The 16 x 16 pivot block of the sixteen-column panels (TileMat::pivot16 x 16, registers only), alone in its
+// workgroup (PARTNER = 0) or with a second wave that lands on the same SIMD (a workgroup's waves are dealt round-robin
+// over the four SIMDs: wave 4 joins wave 0) and streams independent f64 MFMAs (1), f64 vector FMAs (2), or f32 FMAs
+// (3) for as long as wave 0 works.  Reports shader-clock ticks per pivot block for wave 0.
+template <int PARTNER> __global__ __launch_bounds__(PARTNER ? 320 : 64) void k_pivot_block(double* out, const double* in, int reps)
+{
+    typedef TileMat<7, 4> TM;
+    __shared__ volatile int done;
+    const Block b{(int)(threadIdx.x & 63), 64};
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    if (wave == 0) {
+        const TM::Pos p(b);
+        long long t0 = clock64();
+        double sum = 0;
+        for (int r = 0; r < reps; ++r) {
+            double a[4];
+            // a diagonally dominant symmetric block: row c, columns 4 g .. 4 g + 3
+            for (int j = 0; j < 4; ++j) a[j] = (p.c == 4 * p.g + j ? 20.0 : 0.0) + in[(p.c * 16 + 4 * p.g + j + r) & 1023] + in[((4 * p.g + j) * 16 + p.c + r) & 1023];
+            double dg = 20.0 + 2 * in[(p.c * 17 + r) & 1023], myr = 1.0;
+            TM::pivot16<0>(b, p, a, dg, myr); TM::pivot16<1>(b, p, a, dg, myr); TM::pivot16<2>(b, p, a, dg, myr); TM::pivot16<3>(b, p, a, dg, myr);
+            TM::pivot16<4>(b, p, a, dg, myr); TM::pivot16<5>(b, p, a, dg, myr); TM::pivot16<6>(b, p, a, dg, myr); TM::pivot16<7>(b, p, a, dg, myr);
+            TM::pivot16<8>(b, p, a, dg, myr); TM::pivot16<9>(b, p, a, dg, myr); TM::pivot16<10>(b, p, a, dg, myr); TM::pivot16<11>(b, p, a, dg, myr);
+            TM::pivot16<12>(b, p, a, dg, myr); TM::pivot16<13>(b, p, a, dg, myr); TM::pivot16<14>(b, p, a, dg, myr); TM::pivot16<15>(b, p, a, dg, myr);
+            sum += a[0] + a[1] + a[2] + a[3] + myr;
+        }
+        long long t1 = clock64();
+        out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = sum;
+        if (threadIdx.x == 0) {
+            out[4096 + blockIdx.x] = double(t1 - t0) / reps;
+            done = 1;
+        }
+    } else if (PARTNER && wave == 4) {
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 acc[4];
+        for (int i = 0; i < 4; ++i) acc[i] = d4{in[threadIdx.x & 63], 0.0, 1.0, 2.0};
+        double x0 = in[threadIdx.x & 63], x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+        float f0 = (float)x0, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3;
+        const double m = in[64] * 1e-3, c = in[65];
+        long long n = 0;
+        while (!done) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (PARTNER == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(m, c, acc[i], 0, 0, 0);
+                } else if (PARTNER == 2) {
+                    x0 = __builtin_fma(x0, m, c); x1 = __builtin_fma(x1, m, c); x2 = __builtin_fma(x2, m, c); x3 = __builtin_fma(x3, m, c);
+                } else {
+                    f0 = __builtin_fmaf(f0, (float)m, (float)c); f1 = __builtin_fmaf(f1, (float)m, (float)c);
+                    f2 = __builtin_fmaf(f2, (float)m, (float)c); f3 = __builtin_fmaf(f3, (float)m, (float)c);
+                }
+            }
+            ++n;
+        }
+        out[16384 + (threadIdx.x & 63)] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + x0 + x1 + x2 + x3 + f0 + f1 + f2 + f3;
+        if ((threadIdx.x & 63) == 0) out[8192 + blockIdx.x] = (double)n;
+    }
+}
+
 // accuracy of rcp_ against IEEE division over many magnitudes
 __global__ void k_rcp_err(double* out, const double* in, int reps)
 {
@@ -219,6 +281,10 @@ extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, co
     case 21: hipLaunchKernelGGL(k_mfma_f64<1>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 22: hipLaunchKernelGGL(k_mfma_f64<2>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 23: hipLaunchKernelGGL(k_vfma_tile<8>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 30: hipLaunchKernelGGL(k_pivot_block<0>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 31: hipLaunchKernelGGL(k_pivot_block<1>, dim3(blocks), dim3(320), 0, s, out, in, reps); break;
+    case 32: hipLaunchKernelGGL(k_pivot_block<2>, dim3(blocks), dim3(320), 0, s, out, in, reps); break;
+    case 33: hipLaunchKernelGGL(k_pivot_block<3>, dim3(blocks), dim3(320), 0, s, out, in, reps); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -169,26 +169,11 @@ QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) 
 // 16 copies and a full-latency stall per MFMA -- and the flag that forbids it, -amdgpu-mfma-vgpr-form,
 // crashes clang 22 on some instantiations; so the one-wave form is not built for NBL = 7, whose 28
 // tiles alone are 224 registers.)
-// Two workgroups share a CU, wave w of both on SIMD w -- and the waves of a QP are not equally loaded: the wave that
-// owns the bottom tile row issues 2.3 x the matrix instructions of the one that owns the middle rows, and wave 0 runs
-// the serial vector phases.  With identical roles in both workgroups SIMD 0 carries both heavy waves and its f64 pipe
-// (shared by the MFMAs and the vector FMAs of both waves) bounds the pair.  Every other workgroup therefore takes its
-// roles in reverse wave order: the kernel bodies see a thread index whose wave part is mirrored.  Workgroups j and
-// j + 256 land on one CU when the dispatcher deals round-robin (bit 8), j and j + 8 if it fills a CU first (bit 3).
-QPX_DEV int tile_role_tid(int tid, int nt, int qp)
-{
-#ifdef QPX_NO_ROLE_FLIP
-    return tid;
-#else
-    const bool flip = (((qp >> 3) ^ (qp >> 8)) & 1) != 0;
-    return flip ? (nt - 64 - (tid & ~63)) + (tid & 63) : tid;
-#endif
-}
 template <int NBL, int NW, int NS>
 __global__ __launch_bounds__(64 * NW, 2) void k_ipm_tile(IpmArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{tile_role_tid((int)threadIdx.x, (int)blockDim.x, (int)blockIdx.x), (int)blockDim.x};
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
     ipm_tile_body<NBL, NW, NS>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
 template <int NBL, int NW, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
@@ -213,7 +198,7 @@ template <int NBL, int NW, bool kBw>
 __global__ __launch_bounds__(64 * NW, 2) void k_kkt_tile(KktArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{tile_role_tid((int)threadIdx.x, (int)blockDim.x, (int)blockIdx.x), (int)blockDim.x};
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
     kkt_tile_body<NBL, NW, kBw>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
 template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream)

@@ -154,6 +154,18 @@ struct Block {
     // true in every lane iff `v` is true in some lane of the wave
     QPX_DEV bool any(bool v) const { return __builtin_amdgcn_ballot_w64(v) != 0ull; }
 
+    // Issue priority of this wave among the waves of its SIMD (0 .. 3).  An f64 MFMA holds the SIMD's f64 pipe for
+    // its whole duration (~83 cycles), and a wave that streams them leaves the other wave of the SIMD one vector
+    // instruction per MFMA (scripts/ubench_pivot.py: a serial chain runs 15 x slower beside such a stream).  The
+    // kernels therefore run their MFMA streams at priority 0 and everything else at 3: a chain instruction that is
+    // ready goes before the next matrix instruction of the neighbour.
+    template <int P> QPX_DEV void prio() const
+    {
+#ifndef QPX_NO_PRIO
+        __builtin_amdgcn_s_setprio(P);
+#endif
+    }
+
     // c += A B on the matrix core, A 16x4, B 4x16, one wave (v_mfma_f64_16x16x4_f64).  Lane l gives
     // a = A[l & 15][l >> 4], b = B[l >> 4][l & 15] and holds c[r] = C[(l >> 4) + 4 r][l & 15].
     QPX_DEV void mfma16x16x4(double a, double b, double (&c)[4]) const

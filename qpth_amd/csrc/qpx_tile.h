@@ -535,6 +535,7 @@ template <int NBL, int NW> struct TileMat {
         QPX_PP(2)
         const T zr = flag[0];                 // 0 from here on
         if (zr != T(0)) return false;
+        blk.template prio<0>();               // the matrix-instruction streams yield to the other wave's chains
         // -- operand tiles: b_J = (I + W_strict) X_J
         {
             T wa[4];
@@ -618,6 +619,7 @@ template <int NBL, int NW> struct TileMat {
                 }
             }
         }
+        blk.template prio<3>();
         return true;
     }
 
@@ -626,6 +628,7 @@ template <int NBL, int NW> struct TileMat {
     static QPX_DEV bool ldl_inv(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int m)
     {
         bool ok = true;
+        blk.template prio<3>();
         long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef QPX_PANEL_PROF
         pacc[7] = clock64();

@@ -87,6 +87,8 @@ struct Block {
         return r != 0;
     }
 
+    template <int P> void prio() const {}
+
     // c += A B, A 16x4, B 4x16 (see the HIP header for the lane mapping); products are summed in
     // k order with fused multiply-adds -- the hardware's internal order is not documented, so GPU
     // and emulation agree to rounding, not bit for bit, once this is used
