@@ -85,14 +85,21 @@ def algorithmic_bytes_per_qp(n, m, q, w):
 
 
 def kernel_source_digest():
-    """sha256 over the kernel sources: identifies the BUILD a PMC measurement belongs to (a git commit would
-    change with every documentation edit)."""
+    """sha256 over the kernel sources with comments and white space removed: identifies the CODE a PMC measurement
+    belongs to (a git commit would change with every documentation edit, the raw files with every comment)."""
+    import re
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "qpth_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".h", ".hip", ".inc")) or name == "Makefile":
+            text = open(os.path.join(d, name), "r", errors="replace").read()
+            if name != "Makefile":
+                text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+                text = re.sub(r"//[^\n]*", " ", text)
+            else:
+                text = re.sub(r"#[^\n]*", " ", text)
             hsh.update(name.encode())
-            hsh.update(open(os.path.join(d, name), "rb").read())
+            hsh.update(" ".join(text.split()).encode())
     return hsh.hexdigest()[:16]
 
 

@@ -5,35 +5,20 @@
 // owning wave holds, in register r, element (g + 4 r, c) of the tile.  Two facts about that
 // layout carry the design:
 //
-//   * a panel of four consecutive rows 4 sp .. 4 sp + 3 of a tile is register `sp` of all 64
-//     lanes (row 4 sp + g in lane group g), and a panel of four columns is 16 lanes;
-//   * the B operand (4 x 16, lane (g, c) gives B[g][c]) and the A operand (16 x 4, lane (g, c)
-//     gives A[c][g]) of the rank-4 update are both indexed by (panel column g, position c).
+//   * register r of a tile is a B operand (4 x 16, lane (g, c) gives B[g][c]) for the k-slice of rows g + 4 r as it
+//     stands, and -- scaled per row -- an A operand (16 x 4, lane (g, c) gives A[c][g]) of the transposed tile;
+//   * stored to LDS register by register ([r][lane]) a tile is plain row-major.
 //
-// ldl_inv (T = L~ D L~^T, with W~ = L~^-1 built in place of the eliminated columns, as in
-// qpx_grid.h) is therefore BLOCKED BY FOUR COLUMNS.  Per panel, one LDS publish + one barrier:
-//
-//   publish   X[kk][j], j = 0 .. MP-1: the four "old" panel rows -- W~ entries (j < k0) from the
-//             owner of the panel's tile row, the identity for the panel's own columns, and the
-//             panel's columns read down the matrix (j > k0 + 3) from the owners of those rows;
-//             S = the 4 x 4 pivot block.
-//   every wave factors S redundantly in registers (4 reciprocals, ~50 flops; the result is
-//             uniform, so is the breakdown decision) and forms, per 16 columns J,
-//             b_J[g][c] = sum_{kk' <= g} (L~_pp^-1)[g][kk'] X[kk'][16 J + c]
-//             which is at once: the new W~ rows of the panel (J left of the panel), L~_pp^-1 itself
-//             (the panel's columns), the un-scaled columns v (J right of it), and -- scaled by
-//             -1/d_g -- the A operand of tile row J.
-//   update    one v_mfma_f64_16x16x4 per owned tile below the panel: E += (-l~) b.
-//
-// That is 1 matrix instruction per tile and 4 columns where the thread-grid kernel issues
-// 4 x 28 vector FMAs per thread, and the per-column bookkeeping is paid once per four columns.
+// ldl_inv (T = L~ D L~^T, with W~ = L~^-1 built in place of the eliminated columns, as in qpx_grid.h) is therefore
+// BLOCKED BY SIXTEEN COLUMNS -- one tile column per panel, two barriers per panel; the scheme is described at
+// panel16() below.  (The round-1 form, four columns per panel with the 4 x 4 pivot block factored redundantly by every
+// wave, is kept behind -DQPX_TILE_PANEL4 for same-box A/B: profiles/r02k .. r02p.)
 //
 // NW waves share a QP (NW = 1, 2 or 4).  Tile rows are dealt round-robin from the bottom: wave w
 // owns rows I_p = NBL-1 - p NW - (w or NW-1-w, alternating), p = 0 .. NPOS-1 ("positions"), and keeps tile (I_p, J) in
 // register slot slot(p, J) -- a static index for static (p, J); which row a position is, is a
 // wave-uniform scalar (a compile-time constant when NW = 1).  The tile row Ip of the current
-// panel is a run-time value (the panel code exists 4 times -- once per register index SP --
-// not 4 NBL times), tests against it are scalar branches.
+// panel is a run-time value (the panel code exists once, not NBL times), tests against it are scalar branches.
 //
 // The triangular mat-vecs of the solve (x = -W~^T D^-1 W~ r) and the symmetric mat-vec R z use
 // vector FMAs on the same registers; sums along tile rows and down tile columns go through LDS
