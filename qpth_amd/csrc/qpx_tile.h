@@ -449,7 +449,7 @@ template <int NBL, int NW> struct TileMat {
         }
     }
 
-    static QPX_DEV bool panel16(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, long long (&pacc)[8])
+    static QPX_DEV bool panel16(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, int m, long long (&pacc)[8])
     {
         QPX_PP(5)
         T* X = scr + kX;
@@ -458,13 +458,33 @@ template <int NBL, int NW> struct TileMat {
         T* BT = scr + kBT;
         T* flag = scr + kFlag;
         const int k0 = 16 * Ip;
+        const int kmax = m - k0;              // pivots of this block that are not identity padding (>= 16: all)
         bool mine = false;
-        // -- publish
+        // -- the pivot block goes first: its owner reads it back (lane (g, c) = row c, columns 4 g .. 4 g + 3, and the
+        // row's diagonal entry) while the rest of the publish is still on its way to LDS
+#pragma unroll
+        for (int pp = 0; pp < NPOS; ++pp) {
+            if (p.row(pp) != Ip) continue;
+            mine = true;
+#pragma unroll
+            for (int J = 0; J < psize(pp); ++J) {
+                if (J != Ip) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(p.g + 4 * r) * SS + p.c] = E.e[slot(pp, J)][r];
+            }
+        }
+        T a[4] = {T(0), T(0), T(0), T(0)}, dg = T(1), myr = T(1);
+        if (mine) {
+            blk.wave_sync();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
+            dg = S[p.c * SS + p.c];
+        }
+        // -- publish the panel's sixteen old rows
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
             const int I = p.row(pp);
             if (I < Ip) continue;
-            if (I == Ip) mine = true;
 #pragma unroll
             for (int J = 0; J < psize(pp); ++J) {
                 if (J > Ip) continue;
@@ -472,9 +492,6 @@ template <int NBL, int NW> struct TileMat {
                     if (J < Ip) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) X[(p.g + 4 * r) * XS + 16 * J + p.c] = E.e[slot(pp, J)][r];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) S[(p.g + 4 * r) * SS + p.c] = E.e[slot(pp, J)][r];
                     }
                 } else if (J == Ip) {
 #pragma unroll
@@ -483,31 +500,27 @@ template <int NBL, int NW> struct TileMat {
             }
         }
         QPX_PP(0)
-        // -- the pivot block, by the wave that owns it
+        // -- the pivot block, by the wave that owns it.  Pivots of the identity padding are skipped (d = 1, no
+        // multipliers): their columns of W are zero.
         if (mine) {
-            blk.wave_sync();
-            T a[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
-            T dg = S[p.c * SS + p.c], myr = T(1);
             pivot16<0>(blk, p, a, dg, myr);
-            pivot16<1>(blk, p, a, dg, myr);
-            pivot16<2>(blk, p, a, dg, myr);
-            pivot16<3>(blk, p, a, dg, myr);
-            pivot16<4>(blk, p, a, dg, myr);
-            pivot16<5>(blk, p, a, dg, myr);
-            pivot16<6>(blk, p, a, dg, myr);
-            pivot16<7>(blk, p, a, dg, myr);
-            pivot16<8>(blk, p, a, dg, myr);
-            pivot16<9>(blk, p, a, dg, myr);
-            pivot16<10>(blk, p, a, dg, myr);
-            pivot16<11>(blk, p, a, dg, myr);
-            pivot16<12>(blk, p, a, dg, myr);
-            pivot16<13>(blk, p, a, dg, myr);
-            pivot16<14>(blk, p, a, dg, myr);
-            pivot16<15>(blk, p, a, dg, myr);
+            if (kmax > 1) pivot16<1>(blk, p, a, dg, myr);
+            if (kmax > 2) pivot16<2>(blk, p, a, dg, myr);
+            if (kmax > 3) pivot16<3>(blk, p, a, dg, myr);
+            if (kmax > 4) pivot16<4>(blk, p, a, dg, myr);
+            if (kmax > 5) pivot16<5>(blk, p, a, dg, myr);
+            if (kmax > 6) pivot16<6>(blk, p, a, dg, myr);
+            if (kmax > 7) pivot16<7>(blk, p, a, dg, myr);
+            if (kmax > 8) pivot16<8>(blk, p, a, dg, myr);
+            if (kmax > 9) pivot16<9>(blk, p, a, dg, myr);
+            if (kmax > 10) pivot16<10>(blk, p, a, dg, myr);
+            if (kmax > 11) pivot16<11>(blk, p, a, dg, myr);
+            if (kmax > 12) pivot16<12>(blk, p, a, dg, myr);
+            if (kmax > 13) pivot16<13>(blk, p, a, dg, myr);
+            if (kmax > 14) pivot16<14>(blk, p, a, dg, myr);
+            if (kmax > 15) pivot16<15>(blk, p, a, dg, myr);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = a[j];
+            for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = (4 * p.g + j < kmax) ? a[j] : T(0);
             if (p.lane < 16) rd[k0 + p.lane] = myr;
             // a pivot that is not positive and finite leaves a reciprocal that is not (negative, NaN from inf - inf or
             // 0 * inf further down, 0 or inf); nothing above traps, so one test of the sixteen reciprocals replaces
@@ -619,7 +632,7 @@ template <int NBL, int NW> struct TileMat {
         pacc[7] = clock64();
 #endif
 #pragma unroll 1
-        for (int Ip = 0; Ip < NBL && ok && 16 * Ip < m; ++Ip) ok = panel16(blk, p, E, scr, rd, Ip, pacc);
+        for (int Ip = 0; Ip < NBL && ok && 16 * Ip < m; ++Ip) ok = panel16(blk, p, E, scr, rd, Ip, m, pacc);
 #ifdef QPX_PANEL_PROF
         if (p.tid == 0) {
             for (int i = 0; i < 6; ++i) atomicAdd(&qpx_panel_prof[i], (unsigned long long)pacc[i]);
