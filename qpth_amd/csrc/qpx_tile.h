@@ -460,31 +460,12 @@ template <int NBL, int NW> struct TileMat {
         const int k0 = 16 * Ip;
         const int kmax = m - k0;              // pivots of this block that are not identity padding (>= 16: all)
         bool mine = false;
-        // -- the pivot block goes first: its owner reads it back (lane (g, c) = row c, columns 4 g .. 4 g + 3, and the
-        // row's diagonal entry) while the rest of the publish is still on its way to LDS
-#pragma unroll
-        for (int pp = 0; pp < NPOS; ++pp) {
-            if (p.row(pp) != Ip) continue;
-            mine = true;
-#pragma unroll
-            for (int J = 0; J < psize(pp); ++J) {
-                if (J != Ip) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(p.g + 4 * r) * SS + p.c] = E.e[slot(pp, J)][r];
-            }
-        }
-        T a[4] = {T(0), T(0), T(0), T(0)}, dg = T(1), myr = T(1);
-        if (mine) {
-            blk.wave_sync();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
-            dg = S[p.c * SS + p.c];
-        }
-        // -- publish the panel's sixteen old rows
+        // -- publish
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
             const int I = p.row(pp);
             if (I < Ip) continue;
+            if (I == Ip) mine = true;
 #pragma unroll
             for (int J = 0; J < psize(pp); ++J) {
                 if (J > Ip) continue;
@@ -492,6 +473,9 @@ template <int NBL, int NW> struct TileMat {
                     if (J < Ip) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) X[(p.g + 4 * r) * XS + 16 * J + p.c] = E.e[slot(pp, J)][r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) S[(p.g + 4 * r) * SS + p.c] = E.e[slot(pp, J)][r];
                     }
                 } else if (J == Ip) {
 #pragma unroll
@@ -503,6 +487,11 @@ template <int NBL, int NW> struct TileMat {
         // -- the pivot block, by the wave that owns it.  Pivots of the identity padding are skipped (d = 1, no
         // multipliers): their columns of W are zero.
         if (mine) {
+            blk.wave_sync();
+            T a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
+            T dg = S[p.c * SS + p.c], myr = T(1);
             pivot16<0>(blk, p, a, dg, myr);
             if (kmax > 1) pivot16<1>(blk, p, a, dg, myr);
             if (kmax > 2) pivot16<2>(blk, p, a, dg, myr);

@@ -39,3 +39,10 @@ done
 python scripts/make_traffic_json.py $PROF/${TAG}_pmc_FETCH_SIZE.txt $PROF/${TAG}_pmc_WRITE_SIZE.txt > $PROF/ipm_traffic.json 2>> $OUT/summary.txt
 cat $PROF/ipm_traffic.json >> $OUT/summary.txt
 du -sh $OUT | tee -a $OUT/summary.txt
+# same-box A/B against reference builds, when they travel with the snapshot (qpth_amd/libqpx_hip_<tag>.so)
+if ls qpth_amd/libqpx_hip_r02q.so > /dev/null 2>&1; then
+  echo "== A/B on this box (r02q = the previous measured build, p4 = four-column panels)" | tee -a $OUT/summary.txt
+  timeout 300 python scripts/ab_bench.py $(ls qpth_amd/libqpx_hip_p4.so qpth_amd/libqpx_hip_r02q.so 2>/dev/null) qpth_amd/libqpx_hip.so 2>&1 | grep -v amdgpu.ids | tee $PROF/${TAG}_ab_c2.txt >> $OUT/summary.txt
+  timeout 300 python scripts/ab_bench.py qpth_amd/libqpx_hip_r02q.so qpth_amd/libqpx_hip.so 8192 64 64 0 2>&1 | grep -v amdgpu.ids | tee $PROF/${TAG}_ab_c5shape.txt >> $OUT/summary.txt
+  timeout 300 python scripts/ab_bench.py qpth_amd/libqpx_hip_r02q.so qpth_amd/libqpx_hip.so 512 100 50 10 2>&1 | grep -v amdgpu.ids | tee $PROF/${TAG}_ab_c3.txt >> $OUT/summary.txt
+fi
