@@ -198,8 +198,9 @@ def main():
                     help="Q, G, A shared by the batch (SURVEY 8f-1): one pre-factorisation for the whole batch, "
                          "shared-parameter gradients reduced by qpx_batch_outer (+ all_reduce at N > 1)")
     ap.add_argument("--refine", type=int, default=None,
-                    help="QPFunction(refine=...): finishing iterations on the residuals of the original data (default: "
-                         "automatic = 3 in float32, 0 in float64; 0 = the loop kernel alone)")
+                    help="QPFunction(refine=...).  float32 tensors: default = float64 arithmetic where the float64 tile "
+                         "kernels serve the size (else 2); 0 = the float32 loop kernel alone; k = float32 kernels + k "
+                         "finishing iterations on the residuals of the original data.  float64: default 0")
     ap.add_argument("--table", default=None, choices=["prof-linear", "prof-gurobi"])
     args = ap.parse_args()
 
@@ -299,26 +300,37 @@ def main():
         barrier()
         chunk_ms.append((time.perf_counter() - c0) / 10 * 1e3)
 
+    # float32 data at a size the float64 tile kernels serve runs in float64 arithmetic (QPFunction(refine=None)):
+    # the kernels timed and priced below are then the float64 ones, on the widened tensors
+    from qpth_amd.qp import f64_arithmetic_serves
+    wide = args.dtype == "f32" and args.refine is None and f64_arithmetic_serves(n, m, q)
+    arith = "f64" if wide else args.dtype
     if rank == 0:
         # ---- per-kernel timing with HIP events on the launch stream (torch's current stream) ----
         dQ, dG, dA = tQ.detach(), tG.detach(), tA.detach() if q else tA
+        kp, kh, kb = tp.detach(), th, tb
+        if wide:
+            dQ, dG, dA, kp, kh, kb = [x.double() for x in (dQ, dG, dA, kp, kh, kb)]
+            ones_k, w = ones.double(), 8
+        else:
+            ones_k = ones
         fac = KKTFactors.build(dQ, dG, dA, B)
-        res = fac.ipm(tp.detach(), th, tb)
+        res = fac.ipm(kp, kh, kb)
         torch.cuda.synchronize()
         iters = res.iters.cpu().numpy()
         iters_mean = float(iters.mean())
         nrep = 50 if n + m <= 256 else 5
         t_pre = time_launches(lambda: KKTFactors.build(dQ, dG, dA, B), nrep)
-        t_ipm = time_launches(lambda: fac.ipm(tp.detach(), th, tb), nrep)
+        t_ipm = time_launches(lambda: fac.ipm(kp, kh, kb), nrep)
         want_p = (False, True, False, False, False, False)
-        t_bwd = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones, want=want_p), nrep)
-        t_bwd_all = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones), nrep)
+        t_bwd = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones_k, want=want_p), nrep)
+        t_bwd_all = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones_k), nrep)
         set_stall_policy(_lib.STALL_OFF)
-        t_ipm_fixed = time_launches(lambda: fac.ipm(tp.detach(), th, tb), max(3, nrep // 3))
+        t_ipm_fixed = time_launches(lambda: fac.ipm(kp, kh, kb), max(3, nrep // 3))
         set_stall_policy(None)
-        # forward only = BASELINE.json configs[1] as written (QPFunction forward, no backward)
+        # forward only = BASELINE.json configs[1] as written (QPFunction forward, no backward), on the caller's tensors
         with torch.no_grad():
-            t_fwd = time_launches(lambda: qpf(dQ, tp.detach(), dG, th, dA, tb), nrep)
+            t_fwd = time_launches(lambda: qpf(tQ.detach(), tp.detach(), tG.detach(), th, tA.detach() if q else tA, tb), nrep)
 
         fwd_r, fwd_w, bwd_r, bwd_w = algorithmic_bytes_per_qp(n, m, q, w)
         ipm_bytes = (fwd_r + fwd_w) * B          # the forward's compulsory traffic, DESIGN.md section 6
@@ -326,13 +338,13 @@ def main():
         # its roofline is the dense matrix/vector peak of the dtype it computes in.
         ipm_flops = algorithmic_flops_per_qp(n, m, q, iters_mean) * B
         achieved = ipm_flops / t_ipm
-        peak = MFMA_PEAK[args.dtype]
+        peak = MFMA_PEAK[arith]
         traffic, traffic_note = None, "no PMC record for this configuration"
         tf = os.path.join(ROOT, "profiles", "ipm_traffic.json")
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf))
-                if rec.get("config") != [B, n, m, q, args.dtype]:
+                if rec.get("config") != [B, n, m, q, arith]:
                     traffic_note = "PMC record is for config %s" % rec.get("config")
                 elif rec.get("kernel_source_digest") != kernel_source_digest():
                     traffic_note = "PMC record is of another build (%s); re-run scripts/gpu_check.sh" % rec.get("kernel_source_digest")
@@ -352,7 +364,7 @@ def main():
         # alone through the measurement hook and priced against the f64/f32 matrix-core peak: m^2 n flops per QP
         # (one triangle of the symmetric product), Zt read + R written per QP.
         lib = _lib.hip()
-        code = _lib.QPX_F64 if args.dtype == "f64" else _lib.QPX_F32
+        code = _lib.QPX_F64 if arith == "f64" else _lib.QPX_F32
         stream = torch.cuda.current_stream(dev).cuda_stream
         blob_ptr = ctypes.c_void_p(fac.blob.data_ptr())
         with fac._knob():
@@ -414,7 +426,7 @@ def main():
             "metric": "QPs/sec (fwd+bwd) at batch=512 nz=100 nineq=100; 1/2/4/8 MI355X",
             "value": value, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": arith, "data": "synthetic",
             "config": {"workload": "%s fwd+bwd: batch=%d nz=%d nineq=%d neq=%d %s, dense random QP (prof-linear.py "
                                    "generator)%s, QPFunction(verbose=-1%s) defaults, p requires grad%s"
                                    % (names[args.config], Bcfg, n, m, q, "GLOBAL (sharded)" if strong else "per GPU",
@@ -422,6 +434,9 @@ def main():
                                       "" if args.refine is None else ", refine=%d" % args.refine,
                                       ", zhat all_gathered over RCCL" if gather else ""),
                        "global_batch": global_B, "parallelism": "batch-sharded x%d" % world,
+                       "tensor_dtype": args.dtype,
+                       "arithmetic": ("float64 kernels on float32 tensors (widened / narrowed on the device inside the "
+                                      "timed step)" if wide else arith),
                        "ipm_iterations_mean": iters_mean, "ipm_iterations_max": int(iters.max()),
                        "ipm_iterations_histogram": np.bincount(iters, minlength=21).tolist()},
             "roofline": roofline,

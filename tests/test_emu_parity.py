@@ -430,9 +430,10 @@ def test_forward_accepts_every_kkt_solver(solver):
 
 
 def test_float32_finishing_steps_reach_the_reference_accuracy():
-    """QPFunction in float32: the loop kernel alone lands ~1e-4 from the float64 answer on the benchmark generator
-    (cond(Q) ~ 1e6); with the default finishing steps (refine=None -> 2) it is as close as the reference's own float32
-    run.  Two QPs of the C2 golden pair on the emulator; the distribution over 32 QPs is asserted on the GPU."""
+    """QPFunction in float32: the loop kernel alone (refine=0) lands ~1e-4 from the float64 answer on the benchmark
+    generator (cond(Q) ~ 1e6); with finishing steps (refine=2) it is as close as the reference's own float32 run, and
+    so is the default at this size (refine=None: float32 data, float64 arithmetic).  Two QPs of the C2 golden pair on
+    the emulator; the distribution over 32 QPs is asserted on the GPU."""
     g = load_golden("f32pair_c2_b32_n100_m100")
     B, n, m, q, seed = [int(v) for v in g["shape"]]
     arrs = [a[:2] if a.size else a for a in problems.prof_qp(B, n, m, q, seed, np.float32)]
@@ -440,7 +441,40 @@ def test_float32_finishing_steps_reach_the_reference_accuracy():
     tq = tens(arrs, torch.float32, grad=False)
     with emulated(256):
         fast = QPFunction(verbose=-1, refine=0)(*tq)
-        good = QPFunction(verbose=-1)(*tq)
+        good = QPFunction(verbose=-1, refine=2)(*tq)
+        wide = QPFunction(verbose=-1)(*tq)
+    assert wide.dtype == torch.float32
     e_fast, e_good, e_ref = rel_err(fast.numpy(), ref64), rel_err(good.numpy(), ref64), rel_err(ref32, ref64)
+    e_wide = rel_err(wide.numpy(), ref64)
     assert (e_good < np.maximum(10 * e_ref, 2e-5)).all(), (e_fast, e_good, e_ref)
     assert (e_good < e_fast).all(), (e_fast, e_good)
+    assert (e_wide < np.maximum(10 * e_ref, 2e-5)).all(), (e_wide, e_ref)
+
+
+@pytest.mark.parametrize("name", ["c3s_b4_n20_m10_q4_f64", "broadcast_b5_n12_m9_q3", "unbatched_n12_m9_q3"])
+def test_float32_data_in_float64_arithmetic(name):
+    """float32 tensors at a size the float64 tile kernels serve (QPFunction(refine=None)): the parameters are widened
+    on the device, the float64 kernels run, and everything the caller sees is float32 again -- equal, to float32
+    rounding, to the float64 run on the same (float32-representable) data; parameters the batch shares stay one
+    factor blob and get their batch-mean gradient."""
+    from qpth_amd.qp import f64_arithmetic_serves
+    g = load_golden(name)
+    arrs32 = [np.asarray(g[k], np.float32) for k in ("Q", "p", "G", "h", "A", "b")]
+    dl = np.asarray(g["dl_dz"], np.float32)
+    assert f64_arithmetic_serves(arrs32[2].shape[-1], arrs32[2].shape[-2], arrs32[4].shape[-2] if arrs32[4].size else 0)
+    z32, g32 = run_qpf(arrs32, dl, dtype=torch.float32)
+    z64, g64 = run_qpf([a.astype(np.float64) for a in arrs32], dl.astype(np.float64))
+    assert z32.dtype == np.float32 and z32.shape == z64.shape
+    assert rel_err(z32, z64).max() < 1e-6
+    for k, a, b_ in zip(("dQ", "dp", "dG", "dh", "dA", "db"), g32, g64):
+        assert (a is None) == (b_ is None), k
+        if a is not None:
+            assert a.dtype == np.float32 and a.shape == b_.shape, k
+            assert np.abs(a - b_).max() <= 1e-6 * max(1.0, np.abs(b_).max()), k
+
+
+def test_float32_sizes_outside_the_tile_kernels_keep_the_float32_kernels():
+    from qpth_amd.qp import f64_arithmetic_serves
+    assert f64_arithmetic_serves(100, 100, 0) and f64_arithmetic_serves(100, 50, 10) and f64_arithmetic_serves(64, 64, 0)
+    assert not f64_arithmetic_serves(2, 200, 0) and not f64_arithmetic_serves(500, 500, 0)
+    assert not f64_arithmetic_serves(100, 100, 10)

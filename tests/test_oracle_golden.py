@@ -65,7 +65,11 @@ def test_prof_configs_batch_semantics(name, tol):
     assert np.allclose(orc_checksum(Q, p, G, h, A, b), g["input_checksum"], rtol=1e-6)
     x, y, z, s, grads, info = orc.qp_forward_backward(Q, p, G, h, A, b, dl_dz=g["dl_dz"])
     assert rel_err(x, g["zhat"]).max() < tol
-    assert rel_err(z, g["lam"]).max() < 10 * tol
+    # duals of a QP with no active constraint only decay towards zero (1e-9 after 20 float32 iterations here, 1e-19
+    # in the reference's run): the error is measured against a floor, not against the norm of that "zero"
+    lam_floor = 1e-6 if dtype == np.float32 else 1e-12
+    lam_err = np.linalg.norm(z - g["lam"], axis=1) / np.maximum(np.linalg.norm(g["lam"], axis=1), lam_floor)
+    assert lam_err.max() < 10 * tol
     gt = 20 * tol
     for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
         if k in g:
