@@ -2,10 +2,12 @@
 //
 // TEST INFRASTRUCTURE ONLY (see tests/emu/qpx_platform.h).  Pointers are host pointers; the
 // `stream` argument is ignored; workgroups run one after the other, each as QPX_EMU_THREADS
-// (default 128 = two waves) pthreads over a heap-allocated "LDS".
+// (default 128 = two waves) fibers of the calling thread (pthreads with -DQPX_EMU_PTHREADS: the sanitizer
+// drivers) over a heap-allocated "LDS".
 #include <pthread.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -45,6 +47,7 @@ static int emu_threads()
     return (nt / 64) * 64;
 }
 
+#ifdef QPX_EMU_PTHREADS
 template <class Body> struct ThreadCtx {
     const Body* body;
     Block blk;
@@ -87,6 +90,158 @@ template <class Body> static void run_block(int nt, const Body& body)
     for (int w = 0; w < nw; ++w) pthread_barrier_destroy(&wb[w]);
     pthread_barrier_destroy(&sh.block_bar);
 }
+#else
+// ---------------------------------------------------------------------------------------------- fibers
+// The GPU threads of one workgroup as user-level contexts of the calling host thread.  A context is a stack pointer:
+// qpx_fiber_switch pushes the callee-saved registers of the System V x86-64 ABI, stores the stack pointer, loads the
+// other context's and pops its registers (nothing in the kernel bodies changes MXCSR or the x87 control word).
+extern "C" void qpx_fiber_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl qpx_fiber_switch
+    .type qpx_fiber_switch,@function
+qpx_fiber_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size qpx_fiber_switch, .-qpx_fiber_switch
+    .section .note.GNU-stack,"",@progbits
+    .text
+)");
+
+struct Fiber {
+    void* sp = nullptr;
+    FiberBar* waits = nullptr;     // the barrier this fiber sleeps at (nullptr: runnable)
+    unsigned gen = 0;              // ... and the generation it arrived in
+    bool done = false;
+};
+struct FiberSched {
+    int nt = 0, cur = 0, ndone = 0;
+    void* main_sp = nullptr;
+    Fiber* f = nullptr;
+    void (*entry)(FiberSched*, int) = nullptr;   // runs the body of fiber `tid`
+    const void* body = nullptr;
+    EmuShared* sh = nullptr;
+};
+static thread_local FiberSched* g_sched = nullptr;
+
+// next runnable fiber after `cur` in round-robin order; -1 = every live fiber sleeps at a barrier nobody can open
+static int fiber_pick(FiberSched* s)
+{
+    for (int k = 1; k <= s->nt; ++k) {
+        const int t = (s->cur + k) % s->nt;
+        Fiber& f = s->f[t];
+        if (f.done) continue;
+        if (f.waits && f.waits->gen == f.gen) continue;
+        return t;
+    }
+    return -1;
+}
+static void fiber_deadlock(FiberSched* s)
+{
+    std::fprintf(stderr, "qpx_emu: dead-lock -- %d of %d GPU threads have finished and the others wait at barriers that "
+                         "not every thread reaches (divergent __syncthreads / wave barrier in a kernel body)\n", s->ndone, s->nt);
+    std::abort();
+}
+void fiber_wait(FiberSched* s, FiberBar* b, int parties)
+{
+    if (++b->count == parties) {       // last arrival: open the next generation and keep running
+        b->count = 0;
+        ++b->gen;
+        return;
+    }
+    Fiber& me = s->f[s->cur];
+    me.waits = b;
+    me.gen = b->gen;
+    const int t = fiber_pick(s);
+    if (t < 0) fiber_deadlock(s);
+    const int from = s->cur;
+    s->cur = t;
+    qpx_fiber_switch(&s->f[from].sp, s->f[t].sp);
+    s->f[from].waits = nullptr;        // resumed: the generation has moved on
+}
+extern "C" void qpx_fiber_entry()
+{
+    FiberSched* s = g_sched;
+    const int tid = s->cur;
+    s->entry(s, tid);
+    s->f[tid].done = true;
+    ++s->ndone;
+    const int t = fiber_pick(s);
+    void* dead;
+    if (t < 0) {
+        if (s->ndone != s->nt) fiber_deadlock(s);
+        qpx_fiber_switch(&dead, s->main_sp);          // the workgroup has finished
+    } else {
+        s->cur = t;
+        qpx_fiber_switch(&dead, s->f[t].sp);
+    }
+    std::abort();                                      // a finished fiber is never resumed
+}
+
+// run `body(block)` for one workgroup
+template <class Body> static void run_block(int nt, const Body& body)
+{
+    constexpr size_t kStack = 1 << 20;
+    EmuShared sh;
+    const int nw = nt / kWave;
+    std::vector<FiberBar> wb(nw);
+    sh.wave_bar = wb.data();
+    std::vector<unsigned long long> xchg(nt, 0);
+    sh.xchg = xchg.data();
+    std::vector<unsigned long long> xchg2(nt, 0);
+    sh.xchg2 = xchg2.data();
+    std::vector<double> xv((size_t)nt * 16, 0.0);
+    sh.xv = xv.data();
+    // stacks: untouched pages of a fresh allocation cost nothing, so 1 MiB each as for the pthreads
+    static thread_local unsigned char* stacks = nullptr;      // kept for the life of the host thread
+    static thread_local size_t stacks_bytes = 0;
+    if (stacks_bytes < (size_t)nt * kStack + 64) {
+        std::free(stacks);
+        stacks_bytes = (size_t)nt * kStack + 64;
+        stacks = static_cast<unsigned char*>(std::malloc(stacks_bytes));
+        if (!stacks) std::abort();
+    }
+    std::vector<Fiber> fib(nt);
+    FiberSched sc;
+    sc.nt = nt;
+    sc.f = fib.data();
+    sc.body = &body;
+    sc.sh = &sh;
+    sc.entry = [](FiberSched* s, int tid) { (*static_cast<const Body*>(s->body))(Block{tid, s->nt, s->sh}); };
+    sh.sched = &sc;
+    const uintptr_t base = ((uintptr_t)stacks + 63) & ~(uintptr_t)63;
+    for (int t = 0; t < nt; ++t) {
+        // initial frame: six zeroed callee-saved registers, the entry point as the return address of the first
+        // switch, and a null return address above it (the entry function never returns); the stack pointer at
+        // the entry is then 8 mod 16, as after a call
+        uintptr_t top = (base + (size_t)(t + 1) * kStack) & ~(uintptr_t)15;
+        void** p = reinterpret_cast<void**>(top);
+        *--p = nullptr;
+        *--p = reinterpret_cast<void*>(&qpx_fiber_entry);
+        for (int r = 0; r < 6; ++r) *--p = nullptr;
+        fib[t].sp = p;
+    }
+    FiberSched* outer = g_sched;
+    g_sched = &sc;
+    sc.cur = 0;
+    qpx_fiber_switch(&sc.main_sp, fib[0].sp);
+    g_sched = outer;
+    if (sc.ndone != nt) fiber_deadlock(&sc);
+}
+#endif
 
 template <class T, int NS, bool kLds>
 int launch_prefactor(const PrefactorArgs<T>& a, size_t lds_bytes, void*)

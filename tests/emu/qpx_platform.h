@@ -2,10 +2,15 @@
 //
 // TEST INFRASTRUCTURE ONLY.  (Shares the include guard QPX_PLATFORM_H with the HIP header so that
 // including this file first makes qpx_kernels.h compile against the emulation.)  It lets the *same* kernel bodies (qpth_amd/csrc/qpx_kernels.h)
-// run on CPU threads -- one pthread per GPU thread, pthread barriers for __syncthreads and
+// run on the CPU -- one host context per GPU thread, barriers for __syncthreads and
 // for the lock-step exchange behind wave shuffles -- so that indexing, control flow and
-// barrier placement can be checked in the GPU-less build container (and under
-// ThreadSanitizer).  It is compiled into tests/emu/_build/libqpx_emu.so, which only tests
+// barrier placement can be checked in the GPU-less build container.  Two execution modes:
+//   * default: the GPU threads of a workgroup are FIBERS (user-level contexts with their own stacks) of the calling
+//     host thread, switched at barriers by a round-robin scheduler -- no system calls, a barrier that not every
+//     thread reaches is a reported dead-lock instead of a hang (a pthread barrier per shuffle cost ~15 minutes
+//     of futex traffic per test run on an 8-core container);
+//   * -DQPX_EMU_PTHREADS: one pthread per GPU thread with pthread barriers -- what ThreadSanitizer needs to see an
+//     LDS exchange that no barrier orders (tests/emu/Makefile: tsan, asan).  It is compiled into tests/emu/_build/libqpx_emu.so, which only tests
 // load; libqpx_hip.so never contains it and the qpth_amd package never falls back to it.
 #ifndef QPX_PLATFORM_H
 #define QPX_PLATFORM_H
@@ -23,9 +28,26 @@ namespace qpx {
 
 constexpr int kWave = 64;
 
+#ifndef QPX_EMU_PTHREADS
+// A counting barrier for fibers: the last arrival opens the next generation, everybody else asks the scheduler for
+// another runnable fiber until the generation has moved on.
+struct FiberBar {
+    int count = 0;
+    unsigned gen = 0;
+};
+struct FiberSched;
+void fiber_wait(FiberSched* s, FiberBar* b, int parties);      // qpx_emu.cpp
+#endif
+
 struct EmuShared {
+#ifdef QPX_EMU_PTHREADS
     pthread_barrier_t block_bar;   // all threads of the workgroup
     pthread_barrier_t* wave_bar;   // one per wave
+#else
+    FiberBar block_bar;
+    FiberBar* wave_bar;
+    FiberSched* sched;
+#endif
     unsigned long long* xchg;      // one 8-byte exchange slot per thread
     unsigned long long* xchg2;     // a second one (the B operand of the emulated MFMA)
     double* xv;                    // 16 doubles per thread (row_rank1: a whole register row in one round)
@@ -40,17 +62,22 @@ struct Block {
     int wave() const { return tid >> 6; }
     int nwaves() const { return nt >> 6; }
     int uniform(int v) const { return v; }
+#ifdef QPX_EMU_PTHREADS
     void sync() const { pthread_barrier_wait(&sh->block_bar); }
     void wave_sync() const { pthread_barrier_wait(&sh->wave_bar[wave()]); }
+#else
+    void sync() const { fiber_wait(sh->sched, &sh->block_bar, nt); }
+    void wave_sync() const { fiber_wait(sh->sched, &sh->wave_bar[wave()], kWave); }
+#endif
 
     template <class T> T exchange(T v, int src_lane) const
     {
         unsigned long long bits = 0;
         std::memcpy(&bits, &v, sizeof(T));
         sh->xchg[tid] = bits;
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
         bits = sh->xchg[(tid & ~(kWave - 1)) | (src_lane & (kWave - 1))];
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
         T r;
         std::memcpy(&r, &bits, sizeof(T));
         return r;
@@ -70,20 +97,20 @@ struct Block {
     {
         static_assert(N <= 16, "xv holds 16 values per thread");
         for (int j = 0; j < N; ++j) sh->xv[(size_t)tid * 16 + j] = a[j];
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
         const double* src = sh->xv + (size_t)((tid & ~15) | K) * 16;
         for (int j = 0; j < N; ++j) a[j] = std::fma(src[j], m, a[j]);
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
     }
     template <int GK> double grp_bcast(double v) const { return exchange(v, GK * 16 + (lane() & 15)); }
 
     bool any(bool v) const
     {
         sh->xchg[tid] = v ? 1ull : 0ull;
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
         unsigned long long r = 0;
         for (int l = 0; l < kWave; ++l) r |= sh->xchg[(tid & ~(kWave - 1)) | l];
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
         return r != 0;
     }
 
@@ -99,7 +126,7 @@ struct Block {
         std::memcpy(&bb, &b, 8);
         sh->xchg[tid] = ba;
         sh->xchg2[tid] = bb;
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
         const int base = tid & ~(kWave - 1), g = lane() >> 4, cc = lane() & 15;
         for (int r = 0; r < 4; ++r) {
             double acc = c[r];
@@ -111,7 +138,7 @@ struct Block {
             }
             c[r] = acc;
         }
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
     }
     // f32 form: accumulator register r of lane group g is row 4 g + r
     void mfma16x16x4(float a, float b, float (&c)[4]) const
@@ -121,7 +148,7 @@ struct Block {
         std::memcpy(&bb, &b, 4);
         sh->xchg[tid] = ba;
         sh->xchg2[tid] = bb;
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
         const int base = tid & ~(kWave - 1), g = lane() >> 4, cc = lane() & 15;
         for (int r = 0; r < 4; ++r) {
             float acc = c[r];
@@ -133,7 +160,7 @@ struct Block {
             }
             c[r] = acc;
         }
-        pthread_barrier_wait(&sh->wave_bar[wave()]);
+        wave_sync();
     }
     static int mfma_row(double, int g, int r) { return g + 4 * r; }
     static int mfma_row(float, int g, int r) { return 4 * g + r; }
