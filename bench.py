@@ -300,27 +300,23 @@ def main():
         barrier()
         chunk_ms.append((time.perf_counter() - c0) / 10 * 1e3)
 
-    # float32 data at a size the float64 tile kernels serve runs in float64 arithmetic (QPFunction(refine=None)):
-    # the kernels timed and priced below are then the float64 ones, on the widened tensors
+    # float32 data at a size the float64 tile kernels serve runs in float64 arithmetic (QPFunction(refine=None),
+    # QPX_F32_WIDE): the kernels timed and priced below are then the float64 ones, reading and writing float32 tensors
     from qpth_amd.qp import f64_arithmetic_serves
-    wide = args.dtype == "f32" and args.refine is None and f64_arithmetic_serves(n, m, q)
+    wide = (args.dtype == "f32" and args.refine is None and f64_arithmetic_serves(n, m, q)
+            and _lib.hip().dll.qpx_supported(_lib.QPX_F32_WIDE, n, m, q) == 0)
     arith = "f64" if wide else args.dtype
     if rank == 0:
         # ---- per-kernel timing with HIP events on the launch stream (torch's current stream) ----
         dQ, dG, dA = tQ.detach(), tG.detach(), tA.detach() if q else tA
-        kp, kh, kb = tp.detach(), th, tb
-        if wide:
-            dQ, dG, dA, kp, kh, kb = [x.double() for x in (dQ, dG, dA, kp, kh, kb)]
-            ones_k, w = ones.double(), 8
-        else:
-            ones_k = ones
-        fac = KKTFactors.build(dQ, dG, dA, B)
+        kp, kh, kb, ones_k = tp.detach(), th, tb, ones
+        fac = KKTFactors.build(dQ, dG, dA, B, wide=wide)
         res = fac.ipm(kp, kh, kb)
         torch.cuda.synchronize()
         iters = res.iters.cpu().numpy()
         iters_mean = float(iters.mean())
         nrep = 50 if n + m <= 256 else 5
-        t_pre = time_launches(lambda: KKTFactors.build(dQ, dG, dA, B), nrep)
+        t_pre = time_launches(lambda: KKTFactors.build(dQ, dG, dA, B, wide=wide), nrep)
         t_ipm = time_launches(lambda: fac.ipm(kp, kh, kb), nrep)
         want_p = (False, True, False, False, False, False)
         t_bwd = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones_k, want=want_p), nrep)
@@ -364,7 +360,7 @@ def main():
         # alone through the measurement hook and priced against the f64/f32 matrix-core peak: m^2 n flops per QP
         # (one triangle of the symmetric product), Zt read + R written per QP.
         lib = _lib.hip()
-        code = _lib.QPX_F64 if arith == "f64" else _lib.QPX_F32
+        code = _lib.QPX_F32_WIDE if wide else (_lib.QPX_F64 if arith == "f64" else _lib.QPX_F32)
         stream = torch.cuda.current_stream(dev).cuda_stream
         blob_ptr = ctypes.c_void_p(fac.blob.data_ptr())
         with fac._knob():
@@ -435,8 +431,8 @@ def main():
                                       ", zhat all_gathered over RCCL" if gather else ""),
                        "global_batch": global_B, "parallelism": "batch-sharded x%d" % world,
                        "tensor_dtype": args.dtype,
-                       "arithmetic": ("float64 kernels on float32 tensors (widened / narrowed on the device inside the "
-                                      "timed step)" if wide else arith),
+                       "arithmetic": ("float64 kernels on float32 tensors (QPX_F32_WIDE: widened on load, narrowed on store, "
+                                      "float64 factors)" if wide else arith),
                        "ipm_iterations_mean": iters_mean, "ipm_iterations_max": int(iters.max()),
                        "ipm_iterations_histogram": np.bincount(iters, minlength=21).tolist()},
             "roofline": roofline,

@@ -15,7 +15,7 @@
  *   qpx_backward .......... qpth/qp.py:127-182                     QPFunctionFn.backward (per-QP grads)
  *
  * Conventions
- *   - dtype: QPX_F32 or QPX_F64; every `void*` array below has that element type.
+ *   - dtype: QPX_F32 or QPX_F64: every `void*` array below has that element type; or QPX_F32_WIDE (see the enum).
  *   - All pointers are DEVICE pointers valid on `stream` (a hipStream_t).  The caller owns every
  *     buffer; the library never allocates, frees or synchronises.  Calls are stream-ordered and
  *     re-entrant: the only mutable state is the A/B knob of qpx_set_ipm_variant, which is per host
@@ -43,9 +43,15 @@
 extern "C" {
 #endif
 
-#define QPX_ABI_VERSION 3
+#define QPX_ABI_VERSION 4
 
-enum { QPX_F32 = 0, QPX_F64 = 1 };
+/* QPX_F32_WIDE (ABI v4): the caller's arrays are float32, `factors` and all arithmetic are float64 -- every `void*`
+ * array below except `factors` has float elements, `factors` holds qpx_factor_elems(QPX_F32_WIDE, ...) DOUBLES.  On
+ * MI355X the float64 matrix-core kernels are as fast as the float32 thread-grid kernels and return the float64
+ * solution of the float32 data (the float32 kernels iterate on products rounded to float32: ~1e-4 from it on the
+ * reference's benchmark generator).  Served where the thread-grid / tile kernels run (nz+neq+nineq <= 208), else
+ * QPX_ERR_UNSUPPORTED; refine must be 0; qpx_batch_outer takes QPX_F32 for such a caller's float32 vectors. */
+enum { QPX_F32 = 0, QPX_F64 = 1, QPX_F32_WIDE = 2 };
 
 enum {
     QPX_OK = 0,
@@ -80,6 +86,9 @@ size_t qpx_factor_elems(int dtype, int n, int m, int q);
 
 /* largest max(n,m,q) this build can solve; whether (n,m,q) runs with LDS-resident matrices */
 int qpx_max_dim(void);
+/* QPX_OK if (dtype, n, m, q) is served under the calling thread's knob, else the QPX_ERR_* the entry points would
+ * return (QPX_F32_WIDE: QPX_ERR_UNSUPPORTED outside the thread-grid / tile kernels' sizes) */
+int qpx_supported(int dtype, int n, int m, int q);
 int qpx_fits_lds(int dtype, int n, int m, int q);
 
 /* tuning/A-B knob (per host thread): which kernel family runs.  0 (default) = automatic: the thread-grid /

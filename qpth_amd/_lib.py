@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(_HERE, "libqpx_hip.so")
 
-QPX_F32, QPX_F64 = 0, 1
+QPX_F32, QPX_F64, QPX_F32_WIDE = 0, 1, 2      # QPX_F32_WIDE: float32 arrays, float64 factors and arithmetic (include/qpx.h)
 ST_Q_NOT_SPD, ST_A_RANK, ST_KKT_BREAKDOWN, ST_INACCURATE, ST_MAXITER, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 STALL_OFF, STALL_REFERENCE, STALL_FLOOR = 0, 1, 2
 
@@ -29,6 +29,7 @@ _SIGNATURES = {
     "qpx_strerror": (ctypes.c_char_p, [_i]),
     "qpx_factor_elems": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "qpx_max_dim": (_i, []),
+    "qpx_supported": (_i, [_i, _i, _i, _i]),
     "qpx_fits_lds": (_i, [_i, _i, _i, _i]),
     "qpx_set_ipm_variant": (_i, [_i]),
     "qpx_get_ipm_variant": (_i, []),
@@ -54,6 +55,14 @@ def _dtype_code(t):
     if t.dtype == torch.float32:
         return QPX_F32
     raise TypeError("qpth_amd supports float32 and float64 tensors, got %s" % t.dtype)
+
+
+def _code(factors, wide):
+    """dtype code of a call: QPX_F32_WIDE when the caller's arrays are float32 and `factors` is the float64 blob"""
+    if wide:
+        assert factors.dtype == torch.float64
+        return QPX_F32_WIDE
+    return _dtype_code(factors)
 
 
 def _ptr(t):
@@ -88,7 +97,9 @@ class Param:
 
 
 class QpxLib:
-    def __init__(self, path):
+    def __init__(self, path, strict=True):
+        """strict=False (scripts/ab_bench.py only): an older build of the library -- symbols it lacks are skipped and
+        its ABI version is not checked; the product path always loads strictly."""
         if not os.path.exists(path):
             raise RuntimeError(
                 "qpth_amd: %s is missing. Build the gfx950 extension first "
@@ -97,9 +108,11 @@ class QpxLib:
         self.path = path
         self.dll = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
+            if not strict and not hasattr(self.dll, name):
+                continue
             fn = getattr(self.dll, name)       # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if self.dll.qpx_abi_version() != 3:
+        if strict and self.dll.qpx_abi_version() != 4:
             raise RuntimeError("qpth_amd: ABI version mismatch in %s" % path)
 
     def check(self, code):
@@ -110,18 +123,18 @@ class QpxLib:
         return int(self.dll.qpx_factor_elems(dtype_code, n, m, q))
 
     # -- batch.py:375-429 ---------------------------------------------------------------
-    def pre_factor(self, B, n, m, q, Q, G, A, factors, status):
+    def pre_factor(self, B, n, m, q, Q, G, A, factors, status, wide=False):
         Qp, Gp, Ap = Param(Q, 3), Param(G, 3), Param(A, 3)
         self.check(self.dll.qpx_pre_factor(
-            _dtype_code(factors), B, n, m, q, Qp.ptr, Qp.stride, Gp.ptr, Gp.stride, Ap.ptr, Ap.stride,
+            _code(factors, wide), B, n, m, q, Qp.ptr, Qp.stride, Gp.ptr, Gp.stride, Ap.ptr, Ap.stride,
             _ptr(factors), _ptr(status), _stream(factors)))
 
     # -- batch.py:47-207 ----------------------------------------------------------------
     def ipm(self, B, n, m, q, p, h, b, factors, sfac, eps, maxIter, notImprovedLim, stall_policy,
-            zhat, nu, lam, slack, iters, status, best_resid, trace=None):
+            zhat, nu, lam, slack, iters, status, best_resid, trace=None, wide=False):
         pp, hp, bp = Param(p, 2), Param(h, 2), Param(b, 2)
         self.check(self.dll.qpx_ipm(
-            _dtype_code(factors), B, n, m, q, pp.ptr, pp.stride, hp.ptr, hp.stride, bp.ptr, bp.stride,
+            _code(factors, wide), B, n, m, q, pp.ptr, pp.stride, hp.ptr, hp.stride, bp.ptr, bp.stride,
             _ptr(factors), int(sfac), float(eps), int(maxIter), int(notImprovedLim), int(stall_policy),
             _ptr(zhat), _ptr(nu), _ptr(lam), _ptr(slack), _ptr(iters), _ptr(status), _ptr(best_resid),
             _ptr(trace), _stream(factors)))
@@ -139,20 +152,20 @@ class QpxLib:
 
     # -- batch.py:435-470 + 349-372 ------------------------------------------------------
     def factor_solve_kkt(self, B, n, m, q, factors, sfac, d, rx, rs, rz, ry, dx, ds, dz, dy, status,
-                         refine=0, Q=None, G=None, A=None):
+                         refine=0, Q=None, G=None, A=None, wide=False):
         Qp, Gp, Ap = Param(Q, 3), Param(G, 3), Param(A, 3)
         self.check(self.dll.qpx_factor_solve_kkt(
-            _dtype_code(factors), B, n, m, q, _ptr(factors), int(sfac), _ptr(d), _ptr(rx), _ptr(rs), _ptr(rz),
+            _code(factors, wide), B, n, m, q, _ptr(factors), int(sfac), _ptr(d), _ptr(rx), _ptr(rs), _ptr(rz),
             _ptr(ry), _ptr(dx), _ptr(ds), _ptr(dz), _ptr(dy), int(refine), Qp.ptr, Qp.stride, Gp.ptr, Gp.stride,
             Ap.ptr, Ap.stride, _ptr(status), _stream(factors)))
 
     # -- qp.py:127-182 --------------------------------------------------------------------
     def backward(self, B, n, m, q, factors, sfac, zhat, lam, slack, nu, dl_dz, dQ, dp, dG, dh, dA, db, status,
-                 dx=None, dz=None, dy=None, refine=0, Q=None, G=None, A=None):
+                 dx=None, dz=None, dy=None, refine=0, Q=None, G=None, A=None, wide=False):
         """Any of dQ..db may be None (gradient not wanted); dx, dz, dy: optional KKT solution outputs."""
         Qp, Gp, Ap = Param(Q, 3), Param(G, 3), Param(A, 3)
         self.check(self.dll.qpx_backward(
-            _dtype_code(factors), B, n, m, q, _ptr(factors), int(sfac), _ptr(zhat), _ptr(lam), _ptr(slack),
+            _code(factors, wide), B, n, m, q, _ptr(factors), int(sfac), _ptr(zhat), _ptr(lam), _ptr(slack),
             _ptr(nu), _ptr(dl_dz), _ptr(dQ), _ptr(dp), _ptr(dG), _ptr(dh), _ptr(dA), _ptr(db),
             _ptr(dx), _ptr(dz), _ptr(dy), int(refine), Qp.ptr, Qp.stride, Gp.ptr, Gp.stride, Ap.ptr, Ap.stride,
             _ptr(status), _stream(factors)))

@@ -415,9 +415,8 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
     const int n = a.n, m = a.m, q = a.q, nq = n + q, na = n + q + m;
     const FacLayout lay = fac_layout(n, m, q, a.images);
     T* F = a.fac + (size_t)qp * a.fac_stride;
-    const T* Qg = a.Q + (size_t)qp * a.sQ;
-    const T* Gg = a.G + (size_t)qp * a.sG;
-    const T* Ag = q > 0 ? a.A + (size_t)qp * a.sA : nullptr;
+    const In<T> Qg(a.Q, (size_t)qp * a.sQ, a.io32), Gg(a.G, (size_t)qp * a.sG, a.io32);
+    const In<T> Ag(q > 0 ? a.A : nullptr, (size_t)qp * a.sA, a.io32);
     T* vec2 = lds;                 // 2*MA
     T* dsl = vec2 + 2 * MA;        // 8
     T* vout = dsl + 8;             // MA
@@ -575,21 +574,21 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     const int lane = b.lane();
     const bool w0 = b.wave() == 0;
     const T mT = (T)m;
-    const T* pg = a.p + (size_t)qp * a.sp;
-    const T* hg = a.h + (size_t)qp * a.sh;
-    const T* bg = q > 0 ? a.b + (size_t)qp * a.sb : nullptr;
+    const int io32 = a.io32;
+    const In<T> pg(a.p, (size_t)qp * a.sp, io32), hg(a.h, (size_t)qp * a.sh, io32);
+    const In<T> bg(q > 0 ? a.b : nullptr, (size_t)qp * a.sb, io32);
 
     if (a.status[qp] & (QPX_ST_Q_NOT_SPD | QPX_ST_A_RANK)) {
         const T nanv = Lim<T>::inf() - Lim<T>::inf();
-        for (int i = b.tid; i < n; i += b.nt) a.zhat[(size_t)qp * n + i] = nanv;
+        for (int i = b.tid; i < n; i += b.nt) put_(a.zhat, io32, (size_t)qp * n + i, nanv);
         for (int i = b.tid; i < m; i += b.nt) {
-            a.lam[(size_t)qp * m + i] = nanv;
-            a.slack[(size_t)qp * m + i] = nanv;
+            put_(a.lam, io32, (size_t)qp * m + i, nanv);
+            put_(a.slack, io32, (size_t)qp * m + i, nanv);
         }
-        for (int i = b.tid; i < q; i += b.nt) a.nu[(size_t)qp * q + i] = nanv;
+        for (int i = b.tid; i < q; i += b.nt) put_(a.nu, io32, (size_t)qp * q + i, nanv);
         if (b.tid == 0) {
             a.iters[qp] = 0;
-            a.best_resid[qp] = Lim<T>::inf();
+            put_(a.best_resid, io32, (size_t)qp, Lim<T>::inf());
         }
         return;
     }
@@ -702,8 +701,8 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
                 if (bad) ctrl[kSt] |= QPX_ST_NONFINITE;
                 ctrl[kStop] = stopf;
                 if (a.trace) {
-                    T* tr = a.trace + ((size_t)it * a.B + qp) * 3;
-                    tr[0] = pri; tr[1] = dual; tr[2] = mu;
+                    const size_t tr = ((size_t)it * a.B + qp) * 3;
+                    put_(a.trace, io32, tr, pri); put_(a.trace, io32, tr + 1, dual); put_(a.trace, io32, tr + 2, mu);
                 }
             }
         }
@@ -856,14 +855,14 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         const T bts = sc[kBtau] * sc[kSigz];
         for (int i = lane; i < m; i += kWave) {
             const T bz = vBZ[i];
-            a.lam[(size_t)qp * m + i] = bz;
-            a.slack[(size_t)qp * m + i] = vBS[i];
+            put_(a.lam, io32, (size_t)qp * m + i, bz);
+            put_(a.slack, io32, (size_t)qp * m + i, vBS[i]);
             vA[i] = bz - bts;
         }
         if (lane == 0) {
             a.iters[qp] = iters;
             a.status[qp] |= st;
-            a.best_resid[qp] = bres;
+            put_(a.best_resid, io32, (size_t)qp, bres);
         }
     }
     if (q > 0)
@@ -878,7 +877,7 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
         block_matTvec<T, 2>(b, vX, F + lay.NTn, vTm, q, n);
     }
     Mat::sync(b);
-    for (int i = b.tid; i < n; i += NT) a.zhat[(size_t)qp * n + i] = vX[i];
+    for (int i = b.tid; i < n; i += NT) put_(a.zhat, io32, (size_t)qp * n + i, vX[i]);
     if (q > 0) {
         // nu = -S11^-1 b + NTn p - W^T z'
         for (int r = b.tid; r < q; r += NT) {
@@ -886,7 +885,7 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
             for (int c2 = 0; c2 < q; ++c2) acc = fma_(-F[lay.S11i + (size_t)r * q + c2], vTm[c2], acc);
             for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], vP[k], acc);
             for (int j = 0; j < m; ++j) acc = fma_(-F[lay.W + (size_t)j * q + r], vA[j], acc);
-            a.nu[(size_t)qp * q + r] = acc;
+            put_(a.nu, io32, (size_t)qp * q + r, acc);
         }
     }
     QPX_PROF(7)
@@ -930,10 +929,13 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
     T* vCY = vCZ + v;
     T* scr = vCY + v;     // Mat::scratch_elems()
 
-    const T* rxg = kBackward ? (a.dl_dz + (size_t)qp * n) : (a.rx ? a.rx + (size_t)qp * n : nullptr);
-    const T* rsg = (!kBackward && a.rs) ? a.rs + (size_t)qp * m : nullptr;
-    const T* rzg = (!kBackward && a.rz) ? a.rz + (size_t)qp * m : nullptr;
-    const T* ryg = (!kBackward && a.ry && q > 0) ? a.ry + (size_t)qp * q : nullptr;
+    const int io32 = a.io32;
+    const In<T> rxg(kBackward ? a.dl_dz : a.rx, (size_t)qp * n, io32);
+    const In<T> rsg(kBackward ? nullptr : a.rs, (size_t)qp * m, io32);
+    const In<T> rzg(kBackward ? nullptr : a.rz, (size_t)qp * m, io32);
+    const In<T> ryg((!kBackward && q > 0) ? a.ry : nullptr, (size_t)qp * q, io32);
+    const In<T> lamg(kBackward ? a.lam : nullptr, (size_t)qp * m, io32), slg(kBackward ? a.slack : nullptr, (size_t)qp * m, io32);
+    const In<T> dg(kBackward ? nullptr : a.d, (size_t)qp * m, io32);
 
     for (int i = b.tid; i < n; i += NT) vRX[i] = rxg ? rxg[i] : T(0);
     for (int i = b.tid; i < q; i += NT) vRY[i] = ryg ? ryg[i] : T(0);
@@ -942,10 +944,10 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
         if (i < m) {
             T d;
             if (kBackward) {
-                const T l = a.lam[(size_t)qp * m + i], sl = a.slack[(size_t)qp * m + i];
+                const T l = lamg[i], sl = slg[i];
                 d = ((l < T(1e-8)) ? T(1e-8) : l) / ((sl < T(1e-8)) ? T(1e-8) : sl);      // qp.py:148
             } else {
-                d = a.d[(size_t)qp * m + i];
+                d = dg[i];
             }
             dinv = T(1) / d;
             rhs = (rsg ? rsg[i] * dinv : T(0)) - (rzg ? rzg[i] : T(0));
@@ -1000,7 +1002,7 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
     // Iterative refinement on the residual of the ORIGINAL KKT system (batch.py:244-270, solve_kkt_ir; the factor
     // is re-used, not re-computed as there):  res = K sol + rhs  with the caller's Q, G, A,  sol += K~^-1 (-res).
     //   resx = Q dx + G^T dz + A^T dy + rx,   resz = G dx + ds + rz  (ds = (-rs - dz)/d, so ress = 0),   resy = A dx + ry
-    if (a.refine > 0 && a.Q && a.G) {
+    if (a.refine > 0 && a.Q && a.G && !io32) {
         const T* Qg = a.Q + (size_t)qp * a.sQ;
         const T* Gg = a.G + (size_t)qp * a.sG;
         const T* Ag = (q > 0 && a.A) ? a.A + (size_t)qp * a.sA : nullptr;
@@ -1032,52 +1034,53 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
         }
     }
     if (!kBackward) {
-        for (int i = b.tid; i < n; i += NT) a.dx[(size_t)qp * n + i] = vDX[i];
+        for (int i = b.tid; i < n; i += NT) put_(a.dx, io32, (size_t)qp * n + i, vDX[i]);
         for (int i = b.tid; i < m; i += NT) {
-            a.dz[(size_t)qp * m + i] = vDZ[i];
-            a.ds[(size_t)qp * m + i] = (-(rsg ? rsg[i] : T(0)) - vDZ[i]) * vD[i];
+            put_(a.dz, io32, (size_t)qp * m + i, vDZ[i]);
+            put_(a.ds, io32, (size_t)qp * m + i, (-(rsg ? rsg[i] : T(0)) - vDZ[i]) * vD[i]);
         }
-        for (int i = b.tid; i < q; i += NT) a.dy[(size_t)qp * q + i] = vDY[i];
+        for (int i = b.tid; i < q; i += NT) put_(a.dy, io32, (size_t)qp * q + i, vDY[i]);
         return;
     }
     // ---- gradients (qp.py:157-173); a NULL output = that gradient is not wanted (ctx.needs_input_grad)
+    const In<T> zhg(a.zhat, (size_t)qp * n, io32), nug(q > 0 ? a.nu : nullptr, (size_t)qp * q, io32);
     for (int i = b.tid; i < n; i += NT) {
-        vZH[i] = a.zhat[(size_t)qp * n + i];
-        if (a.dp) a.dp[(size_t)qp * n + i] = vDX[i];
+        vZH[i] = zhg[i];
+        if (a.dp) put_(a.dp, io32, (size_t)qp * n + i, vDX[i]);
     }
     for (int i = b.tid; i < m; i += NT) {
-        vLM[i] = a.lam[(size_t)qp * m + i];
-        if (a.dh) a.dh[(size_t)qp * m + i] = -vDZ[i];
+        vLM[i] = lamg[i];
+        if (a.dh) put_(a.dh, io32, (size_t)qp * m + i, -vDZ[i]);
     }
     for (int i = b.tid; i < q; i += NT) {
-        vNU[i] = a.nu[(size_t)qp * q + i];
-        if (a.db) a.db[(size_t)qp * q + i] = -vDY[i];
+        vNU[i] = nug[i];
+        if (a.db) put_(a.db, io32, (size_t)qp * q + i, -vDY[i]);
     }
     // the solution of the backward KKT system itself, for callers that reduce shared-parameter gradients
     // over the batch as one contraction (qpx_batch_outer) instead of B outer products
-    if (a.dx) for (int i = b.tid; i < n; i += NT) a.dx[(size_t)qp * n + i] = vDX[i];
-    if (a.dz) for (int i = b.tid; i < m; i += NT) a.dz[(size_t)qp * m + i] = vDZ[i];
-    if (a.dy) for (int i = b.tid; i < q; i += NT) a.dy[(size_t)qp * q + i] = vDY[i];
+    if (a.dx) for (int i = b.tid; i < n; i += NT) put_(a.dx, io32, (size_t)qp * n + i, vDX[i]);
+    if (a.dz) for (int i = b.tid; i < m; i += NT) put_(a.dz, io32, (size_t)qp * m + i, vDZ[i]);
+    if (a.dy) for (int i = b.tid; i < q; i += NT) put_(a.dy, io32, (size_t)qp * q + i, vDY[i]);
     Mat::sync(b);
     if (a.dQ) {
-        T* dQ = a.dQ + (size_t)qp * n * n;
+        const size_t o = (size_t)qp * n * n;
         for (int idx = b.tid; idx < n * n; idx += NT) {
             const int r = idx / n, c = idx - r * n;
-            dQ[idx] = T(0.5) * (vDX[r] * vZH[c] + vZH[r] * vDX[c]);
+            put_(a.dQ, io32, o + idx, T(0.5) * (vDX[r] * vZH[c] + vZH[r] * vDX[c]));
         }
     }
     if (a.dG) {
-        T* dG = a.dG + (size_t)qp * m * n;
+        const size_t o = (size_t)qp * m * n;
         for (int idx = b.tid; idx < m * n; idx += NT) {
             const int r = idx / n, c = idx - r * n;
-            dG[idx] = vDZ[r] * vZH[c] + vLM[r] * vDX[c];
+            put_(a.dG, io32, o + idx, vDZ[r] * vZH[c] + vLM[r] * vDX[c]);
         }
     }
     if (q > 0 && a.dA) {
-        T* dA = a.dA + (size_t)qp * q * n;
+        const size_t o = (size_t)qp * q * n;
         for (int idx = b.tid; idx < q * n; idx += NT) {
             const int r = idx / n, c = idx - r * n;
-            dA[idx] = vDY[r] * vZH[c] + vNU[r] * vDX[c];
+            put_(a.dA, io32, o + idx, vDY[r] * vZH[c] + vNU[r] * vDX[c]);
         }
     }
 }

@@ -278,6 +278,27 @@ QPX_DEV void block_trsm_lower(const Block& b, const T* P, const T* dinv, int n, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Arrays at the C boundary of a FLOAT64 kernel may be float32 (QPX_F32_WIDE in include/qpx.h: the caller keeps float32
+// tensors, factors and arithmetic are float64; `io32` in the argument blocks below).  In<T> reads, put_ writes such an
+// array through its declared pointer type; the branch is wave-uniform and sits outside every inner loop.  The float32
+// kernels never set io32.
+template <class T> struct In {
+    const T* p;
+    int f32;
+    QPX_DEV In(const T* base, size_t off, int io32) : p(nullptr), f32(sizeof(T) == 8 ? io32 : 0)
+    {
+        if (base) p = f32 ? reinterpret_cast<const T*>(reinterpret_cast<const float*>(base) + off) : base + off;
+    }
+    QPX_DEV explicit operator bool() const { return p != nullptr; }
+    QPX_DEV T operator[](size_t i) const { return f32 ? (T) reinterpret_cast<const float*>(p)[i] : p[i]; }
+};
+template <class T> QPX_DEV void put_(T* base, int io32, size_t i, T v)
+{
+    if (sizeof(T) == 8 && io32) reinterpret_cast<float*>(base)[i] = (float)v;
+    else base[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // kernel argument blocks (plain data, passed by value)
 
 template <class T> struct PrefactorArgs {
@@ -288,6 +309,7 @@ template <class T> struct PrefactorArgs {
     size_t fac_stride;
     int* status;
     int images;                           // blob family / register images of R (qpx_layout.h: fac_layout)
+    int io32 = 0;                         // T = double only: Q, G, A are float32 arrays (QPX_F32_WIDE)
 };
 
 template <class T> struct IpmArgs {
@@ -303,6 +325,7 @@ template <class T> struct IpmArgs {
     T* best_resid;
     T* trace;                             // optional [maxIter][B][3]: pri_resid, dual_resid, mu
     int images;                           // blob family the factors were written in (fac_layout)
+    int io32 = 0;                         // T = double only: every array but `fac` is float32 (QPX_F32_WIDE)
 };
 
 template <class T> struct KktArgs {
@@ -322,6 +345,7 @@ template <class T> struct KktArgs {
     int refine;
     const T *Q, *G, *A;
     long long sQ, sG, sA;
+    int io32 = 0;                         // T = double only: every array but `fac` is float32 (QPX_F32_WIDE; refine = 0)
 };
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB of LDS per workgroup

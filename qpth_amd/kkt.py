@@ -63,9 +63,14 @@ def _pinned_ints(device, count, nring=16):
 
 class KKTFactors:
     @classmethod
-    def build(cls, Q, G, A, nBatch=None):
-        """pre_factor_kkt(Q, G, A)   (batch.py:375-429); enqueues one kernel, no host sync."""
+    def build(cls, Q, G, A, nBatch=None, wide=False):
+        """pre_factor_kkt(Q, G, A)   (batch.py:375-429); enqueues one kernel, no host sync.
+        wide: float32 tensors, float64 factors and arithmetic (QPX_F32_WIDE, include/qpx.h): every later call on these
+        factors takes and returns float32 tensors, the blob is float64."""
         self = cls()
+        self.wide = bool(wide)
+        if self.wide and Q.dtype != torch.float32:
+            raise TypeError("qpth_amd: wide=True is for float32 tensors")
         B = nBatch if nBatch is not None else _batch_of(Q, G, A)
         self.B = B
         self.n = Q.size(-1)
@@ -77,7 +82,7 @@ class KKTFactors:
         self.lib = _lib.backend_for(Q)
         self.dtype, self.device = Q.dtype, Q.device
         self.Q, self.G, self.A = Q, G, (A if self.q else None)     # the original data: iterative refinement evaluates residuals with it
-        code = _lib.QPX_F64 if Q.dtype == torch.float64 else _lib.QPX_F32
+        code = _lib.QPX_F32_WIDE if self.wide else (_lib.QPX_F64 if Q.dtype == torch.float64 else _lib.QPX_F32)
         self.elems = self.lib.factor_elems(code, self.n, self.m, self.q)
         # the A/B knob of the library is per host thread and selects the blob layout: remember the value the
         # factors are built under and re-apply it around every later call on them (autograd runs backward
@@ -87,9 +92,10 @@ class KKTFactors:
         self.shared = B > 1 and share_ok and _is_shared(Q, B) and _is_shared(G, B) and _is_shared(A, B)
         nblob = 1 if self.shared else B
         self.sfac = 0 if self.shared else self.elems
-        self.blob = torch.empty(nblob * self.elems, dtype=Q.dtype, device=Q.device)
+        self.blob = torch.empty(nblob * self.elems, dtype=torch.float64 if self.wide else Q.dtype, device=Q.device)
         self.status = torch.empty(B, dtype=torch.int32, device=Q.device)      # every pre-factorisation kernel writes it
-        self.lib.pre_factor(nblob, self.n, self.m, self.q, Q, G, A if self.q else None, self.blob, self.status)
+        self.lib.pre_factor(nblob, self.n, self.m, self.q, Q, G, A if self.q else None, self.blob, self.status,
+                            wide=self.wide)
         if self.shared:
             self.status[1:] = self.status[0]
         # The reference raises on a bad Q / A from inside forward (qp.py:81-85, batch.py:379-386).  The two
@@ -163,7 +169,7 @@ a non-zero diagonal.
         with self._knob():
             self.lib.ipm(B, n, m, q, p, h, b if q else None, self.blob, self.sfac, eps, maxIter, notImprovedLim,
                          stall_policy, r.zhat, r.nu if q else None, r.lam, r.slacks, r.iters, self.status,
-                         r.best_resid, r.trace)
+                         r.best_resid, r.trace, wide=self.wide)
         return r
 
     # -- factor_kkt + solve_kkt (batch.py:435-470, 349-372) ----------------------------------
@@ -180,7 +186,7 @@ a non-zero diagonal.
         with self._knob():
             self.lib.factor_solve_kkt(B, n, m, q, self.blob, self.sfac, d, self._vec(rx, n), self._vec(rs, m),
                                       self._vec(rz, m), self._vec(ry, q), dx, ds, dz, dy, self.status,
-                                      refine=refine, Q=self.Q, G=self.G, A=self.A)
+                                      refine=refine, Q=self.Q, G=self.G, A=self.A, wide=self.wide)
         return dx, ds, dz, dy
 
     # -- KKTSolvers.IR_UNOPT (batch.py:244-270) as a finishing stage --------------------------------
@@ -264,7 +270,7 @@ a non-zero diagonal.
         with self._knob():
             self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m), nv,
                               self._vec(dl_dz, n), dQ, None, dG, None, dA, None, self.status, dx, dz, dy,
-                              refine=refine, Q=self.Q, G=self.G, A=self.A)
+                              refine=refine, Q=self.Q, G=self.G, A=self.A, wide=self.wide)
         if wQ and sQ:
             dQ = torch.empty(n, n, dtype=dt, device=dev)
             self.lib.batch_outer(dx, zh, zh, dx, 0.5, dQ)

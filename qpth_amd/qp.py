@@ -36,9 +36,10 @@ def _print_trace(res):
 
 def f64_arithmetic_serves(nz, nineq, neq):
     """Sizes the float64 matrix-core tile kernels run (qpx_layout.h: tile_nb(nineq) > 0 and grid_nb(nz+neq+nineq) > 0).
-    There a float32 QP is solved in float64 ARITHMETIC (float32 in HBM on the caller's side, float64 in the
-    kernels): on MI355X the f64 matrix-core loop is faster than the f32 thread-grid loop plus its finishing
-    iterations, and its answer is the float64 solution of the float32 data."""
+    There a float32 QP is solved in float64 ARITHMETIC (QPX_F32_WIDE, include/qpx.h: float32 tensors on the caller's
+    side, float64 factors and arithmetic in the kernels, which widen on load and narrow on store): on MI355X the f64
+    matrix-core loop is faster than the f32 thread-grid loop plus its finishing iterations, and its answer is the
+    float64 solution of the float32 data."""
     return nineq <= 112 and nz + neq + nineq <= 208
 
 
@@ -46,9 +47,9 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                maxIter=20, solver=QPSolvers.PDIPM_BATCHED,
                check_Q_spd=True, refine=None):
     """`refine` is the one argument the reference does not have.  For float32 inputs:
-      None (automatic) -- sizes the float64 tile kernels serve (f64_arithmetic_serves): the parameters are widened
-            to float64 on the device, the float64 kernels run, results and gradients are narrowed back to float32;
-            other sizes: as refine=2;
+      None (automatic) -- sizes the float64 tile kernels serve (f64_arithmetic_serves): the float64 kernels run on the
+            float32 tensors (they widen on load and narrow results and gradients on store; the factors between
+            forward and backward are float64); other sizes: as refine=2;
       0  -- the pure float32 kernels, nothing else (fastest at some sizes; the pre-computed products R = G Q^-1 G^T
             carry ~1e-2 relative error in float32 on the benchmark generator, so the loop kernel alone lands 20x
             further from the float64 answer than the reference's float32 run does);
@@ -62,26 +63,25 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
             nBatch = extract_nBatch(Q_, p_, G_, h_, A_, b_)
             nineq, nz = G_.size(-2), G_.size(-1)
             neq = A_.size(-2) if A_.nelement() > 0 else 0
-            # float32 data, float64 arithmetic (see QPFunction.__doc__): widen before expandParam, so that a
-            # parameter the batch shares stays one copy
+            # float32 data, float64 arithmetic (see QPFunction.__doc__)
             ctx.wide = (solver == QPSolvers.PDIPM_BATCHED and refine is None and Q_.dtype == torch.float32
-                        and f64_arithmetic_serves(nz, nineq, neq))
-            ins = [x.double() for x in (Q_, p_, G_, h_, A_, b_)] if ctx.wide else (Q_, p_, G_, h_, A_, b_)
-            Q, _ = expandParam(ins[0], nBatch, 3)
-            p, _ = expandParam(ins[1], nBatch, 2)
-            G, _ = expandParam(ins[2], nBatch, 3)
-            h, _ = expandParam(ins[3], nBatch, 2)
-            A, _ = expandParam(ins[4], nBatch, 3)
-            b, _ = expandParam(ins[5], nBatch, 2)
+                        and f64_arithmetic_serves(nz, nineq, neq)
+                        and _lib.backend_for(Q_).dll.qpx_supported(_lib.QPX_F32_WIDE, nz, nineq, neq) == 0)
+            Q, _ = expandParam(Q_, nBatch, 3)
+            p, _ = expandParam(p_, nBatch, 2)
+            G, _ = expandParam(G_, nBatch, 3)
+            h, _ = expandParam(h_, nBatch, 2)
+            A, _ = expandParam(A_, nBatch, 3)
+            b, _ = expandParam(b_, nBatch, 2)
 
             assert(neq > 0 or nineq > 0)
             ctx.neq, ctx.nineq, ctx.nz = neq, nineq, nz
 
             if solver == QPSolvers.PDIPM_BATCHED:
-                fac = KKTFactors.build(Q, G, A, nBatch)            # qp.py:93
+                fac = KKTFactors.build(Q, G, A, nBatch, wide=ctx.wide)   # qp.py:93
                 res = fac.ipm(p, h, b, eps, maxIter, notImprovedLim,
                               want_trace=(verbose == 1))             # qp.py:94-96
-                ctx.refine = (2 if Q.dtype == torch.float32 else 0) if refine is None else int(refine)
+                ctx.refine = (2 if Q.dtype == torch.float32 and not ctx.wide else 0) if refine is None else int(refine)
                 if ctx.refine > 0:
                     res = fac.polish(p, h, b, res, steps=ctx.refine, refine=1)
                 # one small read-back: the reference raises here too (qp.py:81-85, batch.py:379-386)
@@ -93,8 +93,6 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                         print(pdipm_b.INACC_ERR)                     # batch.py:141-142,205-206
                 ctx.fac = fac
                 zhats, ctx.nus, ctx.lams, ctx.slacks = res.zhat, res.nu, res.lam, res.slacks
-                if ctx.wide:
-                    ctx.zhat_wide, zhats = zhats, zhats.float()      # backward solves with the float64 iterate
             elif solver == QPSolvers.CVXPY:
                 # forward by an external CPU solver, backward by the HIP kernels (qp.py:97-120,142-143)
                 from .solvers import external
@@ -110,8 +108,6 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
         @staticmethod
         def backward(ctx, dl_dzhat):
             zhats, Q, p, G, h, A, b = ctx.saved_tensors
-            if ctx.wide:
-                zhats, dl_dzhat = ctx.zhat_wide, dl_dzhat.double()
             nBatch = extract_nBatch(Q, p, G, h, A, b)
             Q, Q_e = expandParam(Q, nBatch, 3)
             p, p_e = expandParam(p, nBatch, 2)
@@ -134,8 +130,6 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
             want = tuple(ctx.needs_input_grad[:6])
             grads = fac.backward(zhats, ctx.lams, ctx.slacks, ctx.nus, dl_dzhat, want=want,
                                  shared=(Q_e, p_e, G_e, h_e, A_e, b_e), refine=1 if ctx.refine > 0 else 0)
-            if ctx.wide:
-                grads = tuple(g if g is None else g.float() for g in grads)
             if neq == 0:
                 grads = grads[:4] + (None, None)
             return grads

@@ -478,3 +478,61 @@ def test_float32_sizes_outside_the_tile_kernels_keep_the_float32_kernels():
     assert f64_arithmetic_serves(100, 100, 0) and f64_arithmetic_serves(100, 50, 10) and f64_arithmetic_serves(64, 64, 0)
     assert not f64_arithmetic_serves(2, 200, 0) and not f64_arithmetic_serves(500, 500, 0)
     assert not f64_arithmetic_serves(100, 100, 10)
+
+
+def test_f32_wide_abi_surface():
+    """QPX_F32_WIDE (include/qpx.h): float32 arrays, float64 factors -- which sizes it serves, what it refuses, and
+    that the error surface of QPFunction (not SPD, INACC warning, verbose trace) is the same through it."""
+    from qpth_amd import _lib
+    from qpth_amd.kkt import KKTFactors
+    with emulated(64):
+        dll = _lib.backend_for(torch.zeros(1)).dll
+        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 100, 100, 0) == 0
+        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 500, 500, 0) == -2          # the large-QP family has no wide form
+        assert dll.qpx_supported(_lib.QPX_F64, 500, 500, 0) == 0
+        assert dll.qpx_factor_elems(_lib.QPX_F32_WIDE, 100, 100, 0) == dll.qpx_factor_elems(_lib.QPX_F64, 100, 100, 0)
+        old = dll.qpx_set_ipm_variant(1)                                          # workgroup kernels forced: not served
+        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 100, 100, 0) == -2
+        dll.qpx_set_ipm_variant(old)
+        # refinement reads Q, G, A in the kernels' own type: refused, loudly
+        g = load_golden("c3s_b4_n20_m10_q4_f64")
+        tq = tens([np.asarray(g[k], np.float32) for k in ("Q", "p", "G", "h", "A", "b")], torch.float32, grad=False)
+        fac = KKTFactors.build(tq[0], tq[2], tq[4], wide=True)
+        assert fac.blob.dtype == torch.float64
+        d = torch.ones(4, 10)
+        with pytest.raises(RuntimeError, match="code -1"):
+            fac.solve_kkt(d, tq[1], d, d, tq[5], refine=1)
+        # the general KKT solve through the wide interface = the float64 solve of the same data, to float32 rounding
+        outs32 = fac.solve_kkt(d, tq[1], d, d, tq[5])
+        f64 = KKTFactors.build(tq[0].double(), tq[2].double(), tq[4].double())
+        outs64 = f64.solve_kkt(d.double(), tq[1].double(), d.double(), d.double(), tq[5].double())
+        for a_, b_ in zip(outs32, outs64):
+            assert a_.dtype == torch.float32
+            assert (a_.double() - b_).abs().max() <= 2e-6 * max(1.0, float(b_.abs().max()))
+        with pytest.raises(TypeError):
+            KKTFactors.build(tq[0].double(), tq[2].double(), tq[4].double(), wide=True)
+    # error surface
+    Q = -torch.eye(4).unsqueeze(0)
+    p = torch.zeros(1, 4)
+    G = torch.ones(1, 2, 4)
+    h = torch.ones(1, 2)
+    e = torch.empty(0)
+    with emulated(64):
+        with pytest.raises(RuntimeError, match="Q is not SPD."):
+            QPFunction(verbose=-1)(Q, p, G, h, e, e)
+    g = load_golden("c1_b8_n10_m5_f32")
+    tq = tens([g[k] for k in ("Q", "p", "G", "h", "A", "b")], torch.float32, grad=False)
+    buf = io.StringIO()
+    with emulated(64), contextlib.redirect_stdout(buf):
+        z = QPFunction(verbose=1)(*tq)
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("iter: ")]
+    assert len(lines) >= 6 and "nan" not in lines[0]
+    assert rel_err(z.numpy(), load_golden("c1_b8_n10_m5_f64")["zhat"]).max() < 1e-4
+    Q = torch.eye(2).unsqueeze(0)
+    p = torch.zeros(1, 2)
+    G = torch.tensor([[[1.0, 0.0], [-1.0, 0.0]]])
+    h = torch.tensor([[-1.0, -1.0]])
+    buf = io.StringIO()
+    with emulated(64), contextlib.redirect_stdout(buf):
+        QPFunction(verbose=0)(Q, p, G, h, e, e)
+    assert "qpth warning: Returning an inaccurate" in buf.getvalue()
