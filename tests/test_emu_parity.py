@@ -214,6 +214,19 @@ def test_every_loop_kernel_form(variant, shape):
             assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("variant", LOOP_FORMS)
+@pytest.mark.parametrize("name", ["c1_b8_n10_m5_f64", "c3s_b4_n20_m10_q4_f64"])
+def test_every_loop_kernel_form_against_the_reference(variant, name):
+    """... and against the REFERENCE's own outputs (golden vectors, whole-batch semantics): the oracle above runs with
+    this library's per-QP stop rule, which makes that test a cross-form check rather than reference parity."""
+    g = load_golden(name)
+    z, grads = run_qpf([g[k] for k in ("Q", "p", "G", "h", "A", "b")], g["dl_dz"], variant=variant)
+    assert rel_err(z, g["zhat"]).max() < TOL
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g:
+            assert np.abs(gr - g[k]).max() <= 10 * TOL * max(1.0, np.abs(g[k]).max()), k
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_random_shapes_against_the_oracle(seed):
     """Odd sizes on purpose: every padding rule (tiles of 16, panels of 4, slots of 64), neq = 0 and > 0,

@@ -560,6 +560,25 @@ def test_every_loop_kernel_form(dev, variant, shape):
 
 
 # ---------------------------------------------------------------- 5. the bench contract
+@pytest.mark.parametrize("variant", LOOP_FORMS)
+@pytest.mark.parametrize("name", ["c3s_b4_n20_m10_q4_f64", "c2s_b4_n100_m100_f64"])
+def test_every_loop_kernel_form_against_the_reference(dev, variant, name):
+    """The same forms against the REFERENCE's own outputs (golden vectors made by the unmodified reference, whole-batch
+    semantics): test_every_loop_kernel_form above checks them against the oracle run with this library's per-QP stop
+    rule, which is a cross-form check, not reference parity."""
+    from qpth_amd import _lib
+    g = load_golden(name)
+    old = _lib.hip().dll.qpx_set_ipm_variant(variant)
+    try:
+        z, grads = run_qpf(golden_inputs(g), g["dl_dz"], dev)
+    finally:
+        _lib.hip().dll.qpx_set_ipm_variant(old)
+    assert rel_err(z, g["zhat"]).max() < TOL
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g:
+            assert np.abs(gr - g[k]).max() <= 10 * TOL * max(1.0, np.abs(g[k]).max()), k
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields(dev):
     """bench.py is what the driver times: one JSON line on stdout, the metric of BASELINE.json, the roofline
     object of the dominant kernel.  (Short run, no CPU baseline.)"""
