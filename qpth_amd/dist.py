@@ -32,6 +32,11 @@ def gather_batch(local, nBatch, group=None):
     world = dist.get_world_size(group)
     sizes = [shard_bounds(nBatch, r, world) for r in range(world)]
     maxlen = max(hi - lo for lo, hi in sizes)
+    if nBatch % world == 0:
+        # equal slices (the usual case): one collective straight into the full tensor -- no padding, no concatenation
+        out = torch.empty((nBatch,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     pad = torch.zeros((maxlen,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)]

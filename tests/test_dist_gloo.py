@@ -44,6 +44,11 @@ def _worker(rank, world, port, out_dir):
         z_local, z_full = qdist.solve_sharded(QPFunction(verbose=-1), Q, p, tq[2], tq[3], tq[4], tq[5], nB)
         z_local.backward(torch.tensor(g["dl_dz"][lo:hi]))
     dQ = qdist.reduce_shared_grad(Q.grad, hi - lo, nB)
+    # equal slices take the one-collective path of gather_batch (all_gather_into_tensor), unequal ones (nB = 5 above) the padded one
+    even = torch.arange(12, dtype=torch.float64).reshape(3, 4) + 100.0 * rank
+    full = qdist.gather_batch(even, 3 * world)
+    want = torch.cat([torch.arange(12, dtype=torch.float64).reshape(3, 4) + 100.0 * r for r in range(world)], 0)
+    assert torch.equal(full, want)
     dp_full = p.grad.clone()                        # zero outside this rank's rows
     dist.all_reduce(dp_full, op=dist.ReduceOp.SUM)
     if rank == 0:
