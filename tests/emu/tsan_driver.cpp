@@ -1,7 +1,9 @@
 // tests/emu/tsan_driver.cpp -- runs the kernel bodies (host-thread emulation) under ThreadSanitizer.
 // TEST INFRASTRUCTURE ONLY.  One pthread per GPU thread means every LDS exchange that is not ordered by
 // a barrier (__syncthreads / wave-level ordering point) shows up as a data race -- including the ones
-// a GPU would hide by executing a wave in lock step.  Usage: tsan_driver <B> <n> <m> <q> [variant]
+// a GPU would hide by executing a wave in lock step.  Usage: tsan_driver <B> <n> <m> <q> [variant [wide]]
+// ("wide": after the float64 run, the same QPs through QPX_F32_WIDE -- float32 arrays of exactly the right size, so
+// that an I/O site that still indexed them as doubles is a heap overflow under AddressSanitizer)
 // Exit code 0 and no "WARNING: ThreadSanitizer" on stderr = clean.
 #include <cmath>
 #include <cstdio>
@@ -82,5 +84,29 @@ int main(int argc, char** argv)
         printf("qp %d: iters %d status %d best_resid %.2e\n", s, iters[s], status[s], br[s]);
     }
     printf("max constraint violation %.2e\n", worst);
-    return worst < 1e-6 ? 0 : 1;
+    if (worst >= 1e-6) return 1;
+    if (argc > 6) {
+        if (qpx_supported(QPX_F32_WIDE, n, m, q) != 0) { fprintf(stderr, "QPX_F32_WIDE not served at this size / knob\n"); return 4; }
+        auto narrow = [](const std::vector<double>& v, size_t cnt) { std::vector<float> o(cnt); for (size_t i = 0; i < cnt; ++i) o[i] = (float)v[i]; return o; };
+        std::vector<float> Qf = narrow(Q, Q.size()), pf = narrow(p, p.size()), Gf = narrow(G, G.size()), hf = narrow(h, h.size());
+        std::vector<float> Af = narrow(A, (size_t)B * q * n), bf = narrow(bb, (size_t)B * q);
+        std::vector<float> zf((size_t)B * n), nuf((size_t)B * q), lamf((size_t)B * m), slf((size_t)B * m), brf(B), gf((size_t)B * n, 1.0f);
+        std::vector<float> dQf((size_t)B * n * n), dpf((size_t)B * n), dGf((size_t)B * m * n), dhf((size_t)B * m), dAf((size_t)B * q * n), dbf((size_t)B * q);
+        std::vector<float> dxf((size_t)B * n), dzf((size_t)B * m), dyf((size_t)B * q);
+        std::vector<double> facw((size_t)B * qpx_factor_elems(QPX_F32_WIDE, n, m, q));
+        const int64_t few = (int64_t)qpx_factor_elems(QPX_F32_WIDE, n, m, q);
+        rc = qpx_forward(QPX_F32_WIDE, B, n, m, q, Qf.data(), (int64_t)n * n, pf.data(), n, Gf.data(), (int64_t)m * n, hf.data(), m,
+                         q ? Af.data() : nullptr, (int64_t)q * n, q ? bf.data() : nullptr, q, facw.data(), 1e-12, 20, 3, B == 1 ? 1 : 2,
+                         zf.data(), q ? nuf.data() : nullptr, lamf.data(), slf.data(), iters.data(), status.data(), brf.data(), nullptr, nullptr);
+        if (rc) { fprintf(stderr, "wide forward rc %d\n", rc); return 2; }
+        rc = qpx_backward(QPX_F32_WIDE, B, n, m, q, facw.data(), few, zf.data(), lamf.data(), slf.data(), q ? nuf.data() : nullptr, gf.data(),
+                          dQf.data(), dpf.data(), dGf.data(), dhf.data(), q ? dAf.data() : nullptr, q ? dbf.data() : nullptr,
+                          dxf.data(), dzf.data(), q ? dyf.data() : nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, status.data(), nullptr);
+        if (rc) { fprintf(stderr, "wide backward rc %d\n", rc); return 2; }
+        double dz_max = 0, z_max = 0;
+        for (size_t i = 0; i < zf.size(); ++i) { dz_max = std::fmax(dz_max, std::fabs((double)zf[i] - zhat[i])); z_max = std::fmax(z_max, std::fabs(zhat[i])); }
+        printf("QPX_F32_WIDE: max |zhat - zhat_f64| %.2e (max |zhat| %.2e)\n", dz_max, z_max);
+        if (!(dz_max <= 1e-3 * (1.0 + z_max))) return 5;
+    }
+    return 0;
 }
