@@ -79,6 +79,14 @@ class KKTFactors:
         if G.size(-1) != self.n or Q.size(-2) != self.n or (self.q and A.size(-1) != self.n):
             raise RuntimeError("qpth_amd: inconsistent QP sizes Q%s G%s A%s" % (
                 tuple(Q.shape), tuple(G.shape), tuple(A.shape) if A is not None else ()))
+        for X, what in ((Q, "Q"), (G, "G"), (A if self.q else None, "A")):
+            if X is None:
+                continue
+            if X.dtype != Q.dtype or X.device != Q.device:
+                raise RuntimeError("qpth_amd: %s is %s on %s but Q is %s on %s (all of Q, p, G, h, A, b must share one "
+                                   "dtype and one device)" % (what, X.dtype, X.device, Q.dtype, Q.device))
+            if X.dim() not in (2, 3) or (X.dim() == 3 and X.size(0) not in (1, B)):
+                raise RuntimeError("qpth_amd: %s has shape %s for a batch of %d" % (what, tuple(X.shape), B))
         self.lib = _lib.backend_for(Q)
         self.dtype, self.device = Q.dtype, Q.device
         self.Q, self.G, self.A = Q, G, (A if self.q else None)     # the original data: iterative refinement evaluates residuals with it
@@ -140,12 +148,23 @@ a non-zero diagonal.
             raise RuntimeError("qpth_amd Error: A Q^-1 A^T is not positive definite; "
                                "the equality constraints must have full row rank.")
 
-    def _vec(self, X, k):
+    def _check(self, X, k, what, batched_ok=True):
+        """The kernels index raw pointers: a tensor of another dtype, device or shape must never reach them (the
+        reference fails inside bmm / baddbmm with a size or dtype error; here it would be an out-of-bounds read)."""
+        if X.dtype != self.dtype or X.device != self.device:
+            raise RuntimeError("qpth_amd: %s is %s on %s, the factors were built for %s on %s (all of Q, p, G, h, A, b "
+                               "must share one dtype and one device)" % (what, X.dtype, X.device, self.dtype, self.device))
+        shape = tuple(X.shape)
+        if not (shape == (k,) or (batched_ok and shape in ((self.B, k), (1, k)))):
+            raise RuntimeError("qpth_amd: %s has shape %s, expected (%d, %d) or (%d,)" % (what, shape, self.B, k, k))
+
+    def _vec(self, X, k, what="vector"):
         """dense (B,k) contiguous tensor or None"""
         if X is None or X.nelement() == 0 or k == 0:
             return None
-        if X.dim() == 1:
-            X = X.unsqueeze(0).expand(self.B, k)
+        self._check(X, k, what)
+        if X.dim() == 1 or X.size(0) != self.B:
+            X = X.reshape(1, k).expand(self.B, k)
         return X.contiguous()
 
     # -- forward (batch.py:47-207) -------------------------------------------------------
@@ -166,6 +185,12 @@ a non-zero diagonal.
         r.status = self.status
         if stall_policy is None:
             stall_policy = default_stall_policy(B)
+        self._check(p, n, "p")
+        self._check(h, m, "h")
+        if q:
+            if b is None or b.nelement() == 0:
+                raise RuntimeError("qpth_amd: A has %d rows but b is empty" % q)
+            self._check(b, q, "b")
         with self._knob():
             self.lib.ipm(B, n, m, q, p, h, b if q else None, self.blob, self.sfac, eps, maxIter, notImprovedLim,
                          stall_policy, r.zhat, r.nu if q else None, r.lam, r.slacks, r.iters, self.status,
@@ -178,14 +203,14 @@ a non-zero diagonal.
         KKT system (batch.py:228-270, KKTSolvers.IR_UNOPT) inside the kernel, re-using the factorisation."""
         B, n, m, q = self.B, self.n, self.m, self.q
         dt, dev = self.dtype, self.device
-        d = self._vec(d, m)
+        d = self._vec(d, m, "d")
         dx = torch.empty(B, n, dtype=dt, device=dev)
         ds = torch.empty(B, m, dtype=dt, device=dev)
         dz = torch.empty(B, m, dtype=dt, device=dev)
         dy = torch.empty(B, q, dtype=dt, device=dev) if q else None
         with self._knob():
-            self.lib.factor_solve_kkt(B, n, m, q, self.blob, self.sfac, d, self._vec(rx, n), self._vec(rs, m),
-                                      self._vec(rz, m), self._vec(ry, q), dx, ds, dz, dy, self.status,
+            self.lib.factor_solve_kkt(B, n, m, q, self.blob, self.sfac, d, self._vec(rx, n, "rx"), self._vec(rs, m, "rs"),
+                                      self._vec(rz, m, "rz"), self._vec(ry, q, "ry"), dx, ds, dz, dy, self.status,
                                       refine=refine, Q=self.Q, G=self.G, A=self.A, wide=self.wide)
         return dx, ds, dz, dy
 
@@ -266,10 +291,10 @@ a non-zero diagonal.
         dx = buf(need_dx, B, n)                                   # dp = dx  (qp.py:157)
         dz = buf(wh or (wG and sG), B, m)                         # dh = -dz (qp.py:161)
         dy = buf(q > 0 and (wb or (wA and sA)), B, q)             # db = -dy (qp.py:166)
-        zh, lm, nv = self._vec(zhat, n), self._vec(lam, m), self._vec(nu, q)
+        zh, lm, nv = self._vec(zhat, n, "zhat"), self._vec(lam, m, "lam"), self._vec(nu, q, "nu")
         with self._knob():
-            self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m), nv,
-                              self._vec(dl_dz, n), dQ, None, dG, None, dA, None, self.status, dx, dz, dy,
+            self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m, "slacks"), nv,
+                              self._vec(dl_dz, n, "dl_dz"), dQ, None, dG, None, dA, None, self.status, dx, dz, dy,
                               refine=refine, Q=self.Q, G=self.G, A=self.A, wide=self.wide)
         if wQ and sQ:
             dQ = torch.empty(n, n, dtype=dt, device=dev)

@@ -549,3 +549,31 @@ def test_f32_wide_abi_surface():
     with emulated(64), contextlib.redirect_stdout(buf):
         QPFunction(verbose=0)(Q, p, G, h, e, e)
     assert "qpth warning: Returning an inaccurate" in buf.getvalue()
+
+
+def test_mismatched_parameters_are_refused_before_any_kernel_runs():
+    """The kernels index raw pointers, so a parameter of another dtype, batch size or length must never reach them
+    (the reference fails inside bmm / baddbmm; here it would be an out-of-bounds read)."""
+    Q, p, G, h, A, b = [torch.tensor(x) for x in problems.prof_qp(3, 6, 4, 2, 0)]
+    e = torch.empty(0, dtype=torch.float64)
+    bad = {
+        "p is torch.float32": (Q, p.float(), G, h, A, b),
+        "G is torch.float32": (Q, p, G.float(), h, A, b),
+        r"p has shape \(2, 6\)": (Q, p[:2], G, h, A, b),
+        r"G has shape \(2, 4, 6\)": (Q, p, G[:2], h, A, b),
+        r"h has shape \(3, 3\)": (Q, p, G, h[:, :3], A, b),
+        "b is empty": (Q, p, G, h, A, e),
+        "inconsistent QP sizes": (Q[:, :5, :5], p, G, h, A, b),
+    }
+    with emulated(64):
+        for msg, args in bad.items():
+            with pytest.raises(RuntimeError, match=msg):
+                QPFunction(verbose=-1)(*args)
+        with pytest.raises(TypeError, match="float32 and float64"):
+            QPFunction(verbose=-1)(*[x.half() for x in (Q, p, G, h, A, b)])
+        # what IS accepted: non-contiguous views, un-batched vectors, a batch of one given without the batch dimension
+        z0 = QPFunction(verbose=-1)(Q, p, G, h, A, b)
+        z1 = QPFunction(verbose=-1)(Q.transpose(1, 2), p, G, h, A, b)             # Q symmetric
+        assert torch.allclose(z0, z1, rtol=1e-9, atol=1e-12)
+        z2 = QPFunction(verbose=-1)(Q[0], p[0], G[0], h[0], A[0], b[0])
+        assert z2.shape == (1, 6) and torch.allclose(z2[0], z0[0], rtol=1e-9, atol=1e-12)
