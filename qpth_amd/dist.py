@@ -61,3 +61,24 @@ def solve_sharded(qp_function, Q, p, G, h, A, b, nBatch, gather=True, group=None
     if not gather:
         return z_local, None
     return z_local, gather_batch(z_local.detach(), nBatch, group)
+
+
+def forward_sharded(Q, p, G, h, A, b, nBatch, gather=True, group=None, **kw):
+    """The solver-level counterpart of solve_sharded: pre_factor_kkt + forward (qpth/qp.py:92-96) on this rank's slice
+    of the global batch, returning what the reference's forward returns -- zhat, nu, lam, slacks -- for the slice and,
+    if gather, all_gathered to the full batch (the z*, lambda*, nu* a caller keeps for its own backward).  `kw` goes
+    to solvers.pdipm.batch.forward (eps, verbose, notImprovedLim, maxIter, solver)."""
+    from .solvers.pdipm import batch as pdipm_b
+    from .util import expandParam, extract_nBatch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    local_params = shard_params([Q, p, G, h, A, b], nBatch, rank, world)
+    nloc = extract_nBatch(*local_params)
+    # un-batched parameters become stride-0 views over the slice, as in QPFunction (qpth/qp.py:63-70): the solver
+    # entry points take the batch size from Q, G, A
+    lQ, lp, lG, lh, lA, lb = [expandParam(X, nloc, nd)[0] for X, nd in zip(local_params, (3, 2, 3, 2, 3, 2))]
+    Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(lQ, lG, lA)
+    local = pdipm_b.forward(lQ, lp, lG, lh, lA, lb, Q_LU, S_LU, R, **kw)
+    if not gather:
+        return local, None
+    full = tuple(None if v is None else gather_batch(v, nBatch, group) for v in local)
+    return local, full

@@ -51,8 +51,12 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(full, want)
     dp_full = p.grad.clone()                        # zero outside this rank's rows
     dist.all_reduce(dp_full, op=dist.ReduceOp.SUM)
+    # the solver-level path: zhat, nu, lam, slacks of the whole batch on every rank
+    with emulated(64):
+        _, (x_f, nu_f, lam_f, s_f) = qdist.forward_sharded(tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], nB, verbose=-1)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "out.npz"), z=z_full.numpy(), dQ=dQ.numpy(), dp=dp_full.numpy())
+        np.savez(os.path.join(out_dir, "out.npz"), z=z_full.numpy(), dQ=dQ.numpy(), dp=dp_full.numpy(),
+                 x=x_f.numpy(), nu=nu_f.numpy(), lam=lam_f.numpy(), s=s_f.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,6 +69,8 @@ def test_two_rank_batch_sharding(tmp_path):
     assert rel_err(out["z"], g["zhat"]).max() < 1e-6
     assert np.abs(out["dQ"] - g["dQ"]).max() < 1e-6 * max(1.0, np.abs(g["dQ"]).max())
     assert np.abs(out["dp"] - g["dp"]).max() < 1e-6 * max(1.0, np.abs(g["dp"]).max())
+    assert rel_err(out["x"], g["zhat"]).max() < 1e-6 and rel_err(out["nu"], g["nu"]).max() < 1e-6
+    assert rel_err(out["lam"], g["lam"]).max() < 1e-5 and np.abs(out["s"] - g["slacks"]).max() < 1e-6
 
 
 def test_shard_bounds_cover_the_batch():

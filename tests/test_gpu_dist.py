@@ -45,9 +45,12 @@ def _worker(rank, world, port, out_dir):
     dQ = qdist.reduce_shared_grad(Qs.grad, hi - lo, nB)
     dp_full = tp.grad.clone()
     dist.all_reduce(dp_full, op=dist.ReduceOp.SUM)
+    # solver level: zhat, nu, lam, slacks of the global batch gathered over RCCL (what a caller keeps for autograd)
+    _, (x_f, nu_f, lam_f, s_f) = qdist.forward_sharded(Qs.detach(), tp.detach(), tG, th, tA, tb, nB, verbose=-1)
     torch.cuda.synchronize()
     if rank == 0:
-        np.savez(os.path.join(out_dir, "out.npz"), z=z_full.cpu().numpy(), dQ=dQ.cpu().numpy(), dp=dp_full.cpu().numpy())
+        np.savez(os.path.join(out_dir, "out.npz"), z=z_full.cpu().numpy(), dQ=dQ.cpu().numpy(), dp=dp_full.cpu().numpy(),
+                 x=x_f.cpu().numpy(), nu=nu_f.cpu().numpy(), lam=lam_f.cpu().numpy(), s=s_f.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,3 +74,10 @@ def test_rccl_batch_sharding(tmp_path):
     assert rel_err(out["z"], z.detach().cpu().numpy()).max() < 1e-9
     assert np.abs(out["dQ"] - Qs.grad.cpu().numpy()).max() < 1e-9 * max(1.0, Qs.grad.abs().max().item())
     assert np.abs(out["dp"] - tp.grad.cpu().numpy()).max() < 1e-9 * max(1.0, tp.grad.abs().max().item())
+    from qpth_amd.solvers.pdipm import batch as pdipm_b
+    tG, th, tA, tb = [torch.tensor(x, device=dev) for x in (G, h, A, b)]
+    Qe = Qs.detach().unsqueeze(0).expand(nB, n, n)
+    Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(Qe, tG, tA)
+    x1, nu1, lam1, s1 = pdipm_b.forward(Qe, tp.detach(), tG, th, tA, tb, Q_LU, S_LU, R, verbose=-1)
+    assert rel_err(out["x"], x1.cpu().numpy()).max() < 1e-9 and rel_err(out["nu"], nu1.cpu().numpy()).max() < 1e-9
+    assert rel_err(out["lam"], lam1.cpu().numpy()).max() < 1e-9 and np.abs(out["s"] - s1.cpu().numpy()).max() < 1e-9
