@@ -99,7 +99,9 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * 1 = always the workgroup kernels; 3 = the large-QP family whenever neq = 0.
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
- * at 1 / 2 / 4; by default the library picks by dtype, size and batch.
+ * at 1 / 2 / 4; by default the library picks by dtype, size and batch.  Adding 16384 runs the four-wave tile
+ * kernels without their chain wave (the round-2 form: every wave owns tile rows and the pivot blocks are not
+ * eliminated ahead of the trailing updates) -- kept for same-box A/B.
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
  * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
  * synchronisation), 0 = automatic (4 from 64 QPs, 2 from 32); bits 20..27 = initial stagger between the side

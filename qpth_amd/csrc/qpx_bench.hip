@@ -265,6 +265,118 @@ __global__ void k_rcp_err(double* out, const double* in, int reps)
     out[8192 + threadIdx.x] = worst_raw;
 }
 
+// 40. Where do the waves of a workgroup land?  256-thread workgroups shaped like the tile loop kernel (two per CU:
+// launch bounds (256, 2) + ~70 KB of dynamic LDS); every wave records HW_ID (SIMD, CU, SE) and XCC_ID, then the
+// workgroup idles long enough for the whole grid to be co-resident.  out[4096 + 4 * (4 * block + wave) + {0, 1, 2}].
+__global__ __launch_bounds__(256, 2) void k_simd_probe(double* out, const double* in, int reps)
+{
+    extern __shared__ double probe_lds[];
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int wave = threadIdx.x >> 6;
+    probe_lds[threadIdx.x] = in[threadIdx.x];
+    __syncthreads();
+    double x = probe_lds[(threadIdx.x + 1) & 255];
+    const long long t0 = wall_clock64();
+    for (int r = 0; r < reps; ++r) x = __builtin_fma(x, 0.999, 0.001);
+    if ((threadIdx.x & 63) == 0) {
+        double* o = out + 4096 + 4 * (4 * (size_t)blockIdx.x + wave);
+        o[0] = (double)hw; o[1] = (double)xcc; o[2] = (double)t0; o[3] = x;
+    }
+}
+
+// 41 .. 43. The pivot block beside (41) a second wave on the same SIMD that runs the same pivot blocks, (42) an MFMA
+// stream at s_setprio 0 while the pivot wave runs at s_setprio 3, (43) an MFMA stream with gaps (4 MFMAs, then as
+// many idle cycles: a 50 % duty cycle)
+template <int MODE> __global__ __launch_bounds__(320) void k_pivot_pair(double* out, const double* in, int reps)
+{
+    typedef TileMat<7, 4> TM;
+    __shared__ volatile int done;
+    const Block b{(int)(threadIdx.x & 63), 64};
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    if (wave == 0 || (MODE == 1 && wave == 4)) {
+        const TM::Pos p(b);
+        if (MODE == 2 || MODE == 3) __builtin_amdgcn_s_setprio(3);
+        long long t0 = clock64();
+        double sum = 0;
+        for (int r = 0; r < reps; ++r) {
+            double a[4];
+            for (int j = 0; j < 4; ++j) a[j] = (p.c == 4 * p.g + j ? 20.0 : 0.0) + in[(p.c * 16 + 4 * p.g + j + r) & 1023] + in[((4 * p.g + j) * 16 + p.c + r) & 1023];
+            double dg = 20.0 + 2 * in[(p.c * 17 + r) & 1023], myr = 1.0;
+            TM::pivot16<0>(b, p, a, dg, myr); TM::pivot16<1>(b, p, a, dg, myr); TM::pivot16<2>(b, p, a, dg, myr); TM::pivot16<3>(b, p, a, dg, myr);
+            TM::pivot16<4>(b, p, a, dg, myr); TM::pivot16<5>(b, p, a, dg, myr); TM::pivot16<6>(b, p, a, dg, myr); TM::pivot16<7>(b, p, a, dg, myr);
+            TM::pivot16<8>(b, p, a, dg, myr); TM::pivot16<9>(b, p, a, dg, myr); TM::pivot16<10>(b, p, a, dg, myr); TM::pivot16<11>(b, p, a, dg, myr);
+            TM::pivot16<12>(b, p, a, dg, myr); TM::pivot16<13>(b, p, a, dg, myr); TM::pivot16<14>(b, p, a, dg, myr); TM::pivot16<15>(b, p, a, dg, myr);
+            sum += a[0] + a[1] + a[2] + a[3] + myr;
+        }
+        long long t1 = clock64();
+        out[20480 + (blockIdx.x & 63) * 64 + (threadIdx.x & 63)] = sum;
+        if ((threadIdx.x & 63) == 0) {
+            out[(wave == 0 ? 4096 : 12288) + blockIdx.x] = double(t1 - t0) / reps;
+            if (wave == 0) done = 1;
+        }
+    } else if (MODE != 1 && wave == 4) {
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 acc[4];
+        for (int i = 0; i < 4; ++i) acc[i] = d4{in[threadIdx.x & 63], 0.0, 1.0, 2.0};
+        const double m = in[64] * 1e-3, c = in[65];
+        long long n = 0;
+        __builtin_amdgcn_s_setprio(0);
+        while (!done) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(m, c, acc[i], 0, 0, 0);
+            if (MODE == 3) __builtin_amdgcn_s_sleep(5);     // ~320 cycles
+            ++n;
+        }
+        out[16384 + (threadIdx.x & 63)] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+        if ((threadIdx.x & 63) == 0) out[8192 + blockIdx.x] = (double)n;
+    }
+}
+
+// 50. Streams `m` doubles per workgroup through raw_buffer_load_b64 rows (the GlobalRows pattern of the tile loads),
+// 8 B per lane and load, every byte read once: calibration of rocprofv3's FETCH_SIZE for that access width.
+__global__ __launch_bounds__(256) void k_stream_b64(double* out, const double* in, int reps, int m)
+{
+    const Block b{(int)threadIdx.x, 256};
+    const int rows = m / 64;                       // rows of 64 doubles per workgroup
+    const GlobalRows<double> g(in + (size_t)blockIdx.x * m, m, b.lane());
+    double acc = 0;
+    for (int r = b.wave(); r < rows; r += 4) acc += g.row(r);
+    if (acc == 12345.678) out[threadIdx.x] = acc;
+}
+// 51. the same bytes through 16-B-per-lane global loads (the access width the guide's x2 correction is calibrated for)
+__global__ __launch_bounds__(256) void k_stream_b128(double* out, const double* in, int reps, int m)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* src = reinterpret_cast<const d2*>(in + (size_t)blockIdx.x * m);
+    double acc = 0;
+    for (int i = threadIdx.x; i < m / 2; i += 256) { const d2 v = src[i]; acc += v[0] + v[1]; }
+    if (acc == 12345.678) out[threadIdx.x] = acc;
+}
+
+extern "C" int qpx_bench_ptr(int which, int blocks, int reps, int m, double* out, const double* in, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    switch (which) {
+    case 40: {
+        static bool once = false;
+        if (!once) { once = true; hipFuncSetAttribute((const void*)k_simd_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); }
+        hipLaunchKernelGGL(k_simd_probe, dim3(blocks), dim3(256), 72 * 1024, s, out, in, reps);
+        break;
+    }
+    case 41: hipLaunchKernelGGL(k_pivot_pair<1>, dim3(blocks), dim3(320), 0, s, out, in, reps); break;
+    case 42: hipLaunchKernelGGL(k_pivot_pair<2>, dim3(blocks), dim3(320), 0, s, out, in, reps); break;
+    case 43: hipLaunchKernelGGL(k_pivot_pair<3>, dim3(blocks), dim3(320), 0, s, out, in, reps); break;
+    case 50: hipLaunchKernelGGL(k_stream_b64, dim3(blocks), dim3(256), 0, s, out, in, reps, m); break;
+    case 51: hipLaunchKernelGGL(k_stream_b128, dim3(blocks), dim3(256), 0, s, out, in, reps, m); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, const double* in, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;

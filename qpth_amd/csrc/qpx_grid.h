@@ -31,6 +31,9 @@ template <int GS> struct GridPos {
     int tid, a, b;
     static constexpr int NT = GS * GS;
     QPX_DEV explicit GridPos(const Block& blk) : tid(blk.tid), a(blk.tid % GS), b(blk.tid / GS) {}
+    // (the tile kernels' chain-wave form assigns wave roles here and hands the loop's vector work to its chain wave)
+    QPX_DEV void assign(const Block&, int*) {}
+    QPX_DEV bool lead(const Block& blk) const { return blk.wave() == 0; }
     // all threads of the grid reach this point; LDS writes before it are visible after it
     static QPX_DEV void sync(const Block& blk)
     {
@@ -233,6 +236,7 @@ QPX_DEV void grid_solve_neg(const Block& blk, const GridPos<GS>& g, const T (&E)
 template <class T, int GS, int NBL> struct GridMat {
     static constexpr int NT = GS * GS, MP = GS * NBL;
     using Pos = GridPos<GS>;
+    template <class F> static QPX_DEV void with_role(const Pos& p, F&& f) { f(p); }      // (see TileMat::with_role)
     struct Regs { T e[gtri(NBL)]; };
     QPX_LAYOUT_HD static size_t scratch_elems() { return 2 * (size_t)MP + 4 + (size_t)NBL * GS * GS; }
     static QPX_DEV void sync(const Block& blk) { GridPos<GS>::sync(blk); }
@@ -535,11 +539,10 @@ QPX_LAYOUT_HD size_t lds_elems_sweep(int nbl) { return (size_t)3 * 16 * nbl + 8 
 // ------------------------------------------------------------------------------------------
 // The PDIPM loop on the format-3 blob.  Mathematics and control flow: see ipm_body (same
 // reference citations); the factorisation is ldl_inv and every solve is two triangular mat-vecs.
-template <class T, class Mat, int NS>
-QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
+template <class T, class Mat, int NS, class P>
+QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, const P& g)
 {
     constexpr int M8 = Mat::MP, NT = Mat::NT;
-    const typename Mat::Pos g(b);
     const int n = a.n, m = a.m, q = a.q;
     const FacLayout lay = fac_layout(n, m, q, a.images);
     T* F = a.fac + (size_t)qp * a.fac_stride;
@@ -572,7 +575,7 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     T* scr = sc + 24;     // Mat::scratch_elems()
 
     const int lane = b.lane();
-    const bool w0 = b.wave() == 0;
+    const bool w0 = g.lead(b);        // the wave that does the O(m) vector work
     const T mT = (T)m;
     const int io32 = a.io32;
     const In<T> pg(a.p, (size_t)qp * a.sp, io32), hg(a.h, (size_t)qp * a.sh, io32);
@@ -621,11 +624,12 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     // iteration, and carried through the factorisation it cost 32 spilled VGPRs (scratch reloads with
     // a memory round trip each) -- measured on MI355X.
     typename Mat::Regs E;
-    enum { kTau = 0, kBtau, kSigz, kSigs, kBres, kFeasPrev, kAlphaPrev, kMu, kSzdot, kFeas, kResid };
+    enum { kTau = 0, kBtau, kSigz, kSigs, kBres, kFeasPrev, kAlphaPrev, kMu, kSzdot, kFeas, kResid, kGt1 };
     enum { kStop = 0, kNnot, kFloor, kSt, kIters };
     if (b.tid == 0) {
         sc[kTau] = T(1); sc[kBtau] = T(1); sc[kSigz] = T(0); sc[kSigs] = T(0); sc[kBres] = Lim<T>::inf();
         sc[kFeasPrev] = T(0); sc[kAlphaPrev] = T(0);
+        sc[kGt1] = F[lay.scal];          // || G^T 1 ||: read from the blob once, not once per iteration (a global load on the chain)
         ctrl[kStop] = 0; ctrl[kNnot] = 0; ctrl[kFloor] = 0; ctrl[kSt] = 0; ctrl[kIters] = 0;
     }
     for (int i = b.tid; i < M8; i += NT) {
@@ -669,7 +673,7 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
             szdot = wave_sum(b, szdot);
             const T mu = abs_(szdot / mT);
             const T pri = sqrt_(pri2);
-            const T dual = tsz * F[lay.scal];      // || G^T 1 ||
+            const T dual = tsz * sc[kGt1];         // || G^T 1 ||
             const T feas = pri + dual, resid = feas + mT * mu;
             // best iterate and the stop decision, BEFORE the factorisation (as batch.py:118-143 does): the
             // pass that stops costs a mat-vec, not a factorisation
@@ -892,6 +896,15 @@ QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
     QPX_PROF_DUMP(a.trace ? a.trace + (size_t)qp * 8 : (T*)nullptr, T)
 }
 
+// The loop body runs once per wave role (the tile kernels' chain-wave form: Mat::with_role); every other form has one.
+template <class T, class Mat, int NS>
+QPX_DEV void ipm_loop_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
+{
+    typename Mat::Pos g(b);
+    g.assign(b, reinterpret_cast<int*>(lds));      // (an LDS word nothing else uses before the barriers inside)
+    Mat::with_role(g, [&](const auto& gp) { ipm_loop_role<T, Mat, NS>(b, a, qp, lds, gp); });
+}
+
 template <class T, int GS, int NBL, int NS>
 QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
 {
@@ -903,11 +916,10 @@ QPX_DEV void ipm_grid_body(const Block& b, const IpmArgs<T>& a, int qp, T* lds)
 // format-3 blob (see kkt_body for the reference citations):
 //   dz = -T^-1 (M rx + W ry + rs/d - rz),  dx = -K rx - M^T dz - N ry,
 //   dy = S11^-1 ry - N^T rx - W^T dz,      ds = (-rs - dz)/d
-template <class T, class Mat, bool kBackward>
-QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
+template <class T, class Mat, bool kBackward, class P>
+QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, const P& g)
 {
     constexpr int M8 = Mat::MP, NT = Mat::NT;
-    const typename Mat::Pos g(b);
     const int n = a.n, m = a.m, q = a.q;
     const FacLayout lay = fac_layout(n, m, q, a.images);
     T* F = a.fac + (size_t)qp * a.fac_stride;
@@ -1083,6 +1095,14 @@ QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
             put_(a.dA, io32, o + idx, vDY[r] * vZH[c] + vNU[r] * vDX[c]);
         }
     }
+}
+
+template <class T, class Mat, bool kBackward>
+QPX_DEV void kkt_mat_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
+{
+    typename Mat::Pos g(b);
+    g.assign(b, reinterpret_cast<int*>(lds));
+    Mat::with_role(g, [&](const auto& gp) { kkt_mat_role<T, Mat, kBackward>(b, a, qp, lds, gp); });
 }
 
 template <class T, int GS, int NBL, bool kBackward>

@@ -169,16 +169,16 @@ QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) 
 // 16 copies and a full-latency stall per MFMA -- and the flag that forbids it, -amdgpu-mfma-vgpr-form,
 // crashes clang 22 on some instantiations; so the one-wave form is not built for NBL = 7, whose 28
 // tiles alone are 224 registers.)
-template <int NBL, int NW, int NS>
+template <int NBL, int NW, int NS, bool CH>
 __global__ __launch_bounds__(64 * NW, 2) void k_ipm_tile(IpmArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    ipm_tile_body<NBL, NW, NS>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+    ipm_tile_body<NBL, NW, NS, CH>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
-template <int NBL, int NW, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
+template <int NBL, int NW, int NS, bool CH> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
 {
-    auto kern = k_ipm_tile<NBL, NW, NS>;
+    auto kern = k_ipm_tile<NBL, NW, NS, CH>;
     static bool big_lds_enabled = false;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NW), lds_bytes, (hipStream_t)stream, a);
@@ -193,35 +193,44 @@ extern "C" int qpx_panel_prof_read(unsigned long long* out)
     if (hipMemcpyToSymbol(HIP_SYMBOL(qpx_panel_prof), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;
 }
+extern "C" int qpx_chain_prof_read(unsigned long long* out)      // 20 counters of the chain-wave form
+{
+    unsigned long long zero[20] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qpx_chain_prof), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(qpx_chain_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
 #endif
-template <int NBL, int NW, bool kBw>
+template <int NBL, int NW, bool kBw, bool CH>
 __global__ __launch_bounds__(64 * NW, 2) void k_kkt_tile(KktArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    kkt_tile_body<NBL, NW, kBw>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+    kkt_tile_body<NBL, NW, kBw, CH>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
-template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream)
+template <int NBL, int NW, bool kBw, bool CH> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream)
 {
-    auto kern = k_kkt_tile<NBL, NW, kBw>;
+    auto kern = k_kkt_tile<NBL, NW, kBw, CH>;
     static bool big_lds_enabled = false;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NW), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
-#define QPX_INSTK(NBL, NW)                                                                     \
-    template int launch_kkt_tile<NBL, NW, false>(const KktArgs<double>&, size_t, void*);       \
-    template int launch_kkt_tile<NBL, NW, true>(const KktArgs<double>&, size_t, void*);
+#define QPX_INSTK(NBL, NW, CH)                                                                     \
+    template int launch_kkt_tile<NBL, NW, false, CH>(const KktArgs<double>&, size_t, void*);       \
+    template int launch_kkt_tile<NBL, NW, true, CH>(const KktArgs<double>&, size_t, void*);
 #if !defined(QPX_TILE_ONLY)
-QPX_INSTK(1, 1) QPX_INSTK(2, 1) QPX_INSTK(4, 1) QPX_INSTK(4, 2) QPX_INSTK(7, 2) QPX_INSTK(7, 4)
+QPX_INSTK(1, 1, false) QPX_INSTK(2, 1, false) QPX_INSTK(4, 1, false) QPX_INSTK(4, 2, false) QPX_INSTK(7, 2, false)
+QPX_INSTK(7, 4, false) QPX_INSTK(7, 4, true)
 #endif
-#define QPX_INSTT(NBL, NW, NS) template int launch_ipm_tile<NBL, NW, NS>(const IpmArgs<double>&, size_t, void*);
+#define QPX_INSTT(NBL, NW, NS, CH) template int launch_ipm_tile<NBL, NW, NS, CH>(const IpmArgs<double>&, size_t, void*);
 #if defined(QPX_TILE_ONLY)
-QPX_INSTT(7, QPX_TILE_ONLY, 2)
+QPX_INSTT(7, QPX_TILE_ONLY, 2, QPX_TILE_ONLY == 4)
 #else
-QPX_INSTT(1, 1, 1) QPX_INSTT(1, 1, 2) QPX_INSTT(1, 1, 4) QPX_INSTT(2, 1, 1) QPX_INSTT(2, 1, 2) QPX_INSTT(2, 1, 4)
-QPX_INSTT(4, 1, 1) QPX_INSTT(4, 1, 2) QPX_INSTT(4, 1, 4) QPX_INSTT(4, 2, 1) QPX_INSTT(4, 2, 2) QPX_INSTT(4, 2, 4)
-QPX_INSTT(7, 2, 2) QPX_INSTT(7, 2, 4) QPX_INSTT(7, 4, 2) QPX_INSTT(7, 4, 4)
+QPX_INSTT(1, 1, 1, false) QPX_INSTT(1, 1, 2, false) QPX_INSTT(1, 1, 4, false) QPX_INSTT(2, 1, 1, false) QPX_INSTT(2, 1, 2, false)
+QPX_INSTT(2, 1, 4, false) QPX_INSTT(4, 1, 1, false) QPX_INSTT(4, 1, 2, false) QPX_INSTT(4, 1, 4, false) QPX_INSTT(4, 2, 1, false)
+QPX_INSTT(4, 2, 2, false) QPX_INSTT(4, 2, 4, false) QPX_INSTT(7, 2, 2, false) QPX_INSTT(7, 2, 4, false) QPX_INSTT(7, 4, 2, false)
+QPX_INSTT(7, 4, 4, false) QPX_INSTT(7, 4, 2, true) QPX_INSTT(7, 4, 4, true)
 #endif
 #endif
 

@@ -30,8 +30,8 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream);
 // thread-grid kernels (qpx_grid.h), 16x16 threads per QP, format-3 blob
 template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream);
 template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
-template <int NBL, int NW, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream);     // matrix-core tiles, f64, NW waves per QP
-template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream);
+template <int NBL, int NW, int NS, bool CH = false> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream);     // matrix-core tiles, f64, NW waves per QP (CH: chain-wave form)
+template <int NBL, int NW, bool kBw, bool CH = false> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream);
 template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void* stream);   // 8x8 grid = one wave
 template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void* stream);
 

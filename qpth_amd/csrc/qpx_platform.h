@@ -17,6 +17,13 @@
 #define QPX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Make a value opaque to the optimiser at this point (vector / scalar register).  The tile kernels re-derive their LDS
+// addresses from laundered lane coordinates at the top of every panel: otherwise the compiler hoists some sixty
+// loop-invariant address registers and branch conditions out of the interior-point loop, keeps them alive across
+// the whole kernel and spills them (measured: 43 spilled VGPRs in the chain-wave form).
+#define QPX_LAUNDER_V(x) asm volatile("" : "+v"(x))
+#define QPX_LAUNDER_S(x) asm volatile("" : "+s"(x))
+
 namespace qpx {
 
 constexpr int kWave = 64;  // CDNA wavefront width
@@ -31,6 +38,18 @@ struct Block {
     // a value every lane of the wave holds, moved to a scalar register so that branches on it are
     // scalar branches (the compiler cannot see that tid >> 6 is wave-uniform)
     QPX_DEV int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+
+    // The SIMD (0 .. 3) of the CU this wave runs on: HW_ID bits 5:4.  The four waves of a 256-thread workgroup land
+    // on the four SIMDs in the cyclic order 0 -> 2 -> 1 -> 3 from a start that differs between the workgroups of
+    // a CU (profiles/r03a_probes_and_phases.txt), so the wave index says nothing about which waves share a SIMD.
+    QPX_DEV int simd_id() const
+    {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        return (int)((hw >> 4) & 3u);
+    }
+    // *word |= bits, word in LDS (atomic)
+    QPX_DEV void lds_or(int* word, int bits) const { __hip_atomic_fetch_or(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
     // workgroup barrier; LDS and global writes of the workgroup made before it are visible after.
     // The explicit wait is load-bearing: hipcc (ROCm 7.2) dropped the `s_waitcnt lgkmcnt(0)`

@@ -11,11 +11,19 @@
 //
 // ldl_inv (T = L~ D L~^T, with W~ = L~^-1 built in place of the eliminated columns, as in qpx_grid.h) is therefore
 // BLOCKED BY SIXTEEN COLUMNS -- one tile column per panel, two barriers per panel; the scheme is described at
-// panel16() below.  (The round-1 form, four columns per panel with the 4 x 4 pivot block factored redundantly by every
-// wave, is kept behind -DQPX_TILE_PANEL4 for same-box A/B: profiles/r02k .. r02p.)
+// panel16() below.
 //
-// NW waves share a QP (NW = 1, 2 or 4).  Tile rows are dealt round-robin from the bottom: wave w
-// owns rows I_p = NBL-1 - p NW - (w or NW-1-w, alternating), p = 0 .. NPOS-1 ("positions"), and keeps tile (I_p, J) in
+// NW waves share a QP (NW = 1, 2 or 4).  Two forms:
+//   * every wave owns tile rows (CH = false): the wave that owns the pivot block eliminates it while the others wait;
+//   * CHAIN-WAVE form (CH = true, round 3): one wave of the four owns no tiles.  It eliminates the pivot block of
+//     panel k+1 WHILE the three tile-owning waves stream panel k's trailing updates (look-ahead by one panel: the
+//     16 x 16 pivot block is a serial chain of ~3000 cycles, the trailing update of a panel ~2500 cycles of matrix
+//     instructions per wave, and in the first form they ran one after the other), and it does the O(m) vector work
+//     of the interior-point loop.  Which wave that is, is decided by the SIMD it runs on (Pos::assign): an f64 MFMA
+//     holds its SIMD's vector ALU for the whole instruction, so a serial chain must not share a SIMD with a matrix
+//     stream -- the two workgroups of a CU put their chain waves on the same SIMD and their tile waves on the others.
+// Tile rows are dealt round-robin from the bottom over the NWM tile-owning waves: wave w owns rows
+// I_p = NBL-1 - p NWM - (w or NWM-1-w, alternating), p = 0 .. NPOS-1 ("positions"), and keeps tile (I_p, J) in
 // register slot slot(p, J) -- a static index for static (p, J); which row a position is, is a
 // wave-uniform scalar (a compile-time constant when NW = 1).  The tile row Ip of the current
 // panel is a run-time value (the panel code exists once, not NBL times), tests against it are scalar branches.
@@ -37,45 +45,55 @@ static __device__ unsigned long long qpx_panel_prof[8];   // one copy per transl
         pacc[i] += qpx_pp_n - pacc[7];                                   \
         pacc[7] = qpx_pp_n;                                              \
     }
+// chain-wave form: per wave (0 = chain wave, 1 .. 3 = tile waves) the cycles of interval 1 / wait at barrier Y /
+// interval 2 / wait at barrier X, summed over panels: qpx_chain_prof[4 * wave + i]; [16] = factorisations
+static __device__ unsigned long long qpx_chain_prof[20];
+#define QPX_CP(i)                                                        \
+    {                                                                    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      \
+        const long long qpx_cp_n = clock64();                            \
+        cacc[i] += qpx_cp_n - cacc[4];                                   \
+        cacc[4] = qpx_cp_n;                                              \
+    }
 #else
 #define QPX_PP(i)
+#define QPX_CP(i)
 #endif
 
 namespace qpx {
 
-#ifndef QPX_TILE_PANEL4
 // row stride of the panel's X rows (17 mod 32 doubles) and size of the region the mat-vec partials share with the
-// operand tiles of the factorisation
+// operand tiles of the factorisation (nwm = the waves that own tiles)
 QPX_LAYOUT_HD constexpr int tile_xs(int nbl) { return ((16 * nbl - 17 + 31) / 32) * 32 + 17; }
-QPX_LAYOUT_HD constexpr int tile_union(int nbl, int nw)
+QPX_LAYOUT_HD constexpr int tile_union(int nbl, int nwm)
 {
-    const int npos = (nbl + nw - 1) / nw, a = nw * nbl * 64 + nw * 16 * npos * 17, b = nbl * 256;
+    const int npos = (nbl + nwm - 1) / nwm, a = nwm * nbl * 64 + nwm * 16 * npos * 17, b = nbl * 256;
     return a > b ? a : b;
 }
-QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nw)
+QPX_LAYOUT_HD constexpr int tile_union_chain(int nbl, int nwm)      // chain-wave form: BT and its scaled copy AT
 {
-    return (size_t)16 * tile_xs(nbl) + 2 * 16 * 18 + 2 + tile_union(nbl, nw) + 16 * (size_t)nbl;
+    return tile_union(nbl, nwm) > 2 * nbl * 256 ? tile_union(nbl, nwm) : 2 * nbl * 256;
 }
-#else
-QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nw)
+QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nwm, bool chain = false)
 {
-    const size_t mp = 16 * (size_t)nbl, npos = (size_t)(nbl + nw - 1) / nw;
-    return 8 * mp + 32 + (size_t)nw * nbl * 64 + (size_t)nw * 16 * npos * 17 + mp;
+    return (size_t)16 * tile_xs(nbl) + 2 * 16 * 18 + 2 + (chain ? tile_union_chain(nbl, nwm) : tile_union(nbl, nwm)) +
+           16 * (size_t)nbl + (chain ? 256 : 0);
 }
-#endif
 
-template <int NBL, int NW> struct TileMat {
+template <int NBL, int NW, bool CH = false> struct TileMat {
     using T = double;
-    static constexpr int NPOS = (NBL + NW - 1) / NW, NT = 64 * NW, MP = 16 * NBL;
-    static constexpr int psize(int p) { return NBL - p * NW; }            // tiles of position p at most (over the waves)
-    static constexpr int rowof(int p, int w) { return NBL - 1 - p * NW - ((p & 1) ? NW - 1 - w : w); }
+    static_assert(!CH || NW == 4, "the chain-wave form is one chain wave + three tile waves");
+    static constexpr int NWM = CH ? NW - 1 : NW;                           // waves that own tiles
+    static constexpr int NPOS = (NBL + NWM - 1) / NWM, NT = 64 * NW, MP = 16 * NBL;
+    static constexpr int psize(int p) { return NBL - p * NWM; }           // tiles of position p at most (over the waves)
+    static constexpr int rowof(int p, int w) { return NBL - 1 - p * NWM - ((p & 1) ? NWM - 1 - w : w); }
     // Positions 2k and 2k+1 share one run of slots: 2k fills it from the bottom (slot = base + J), 2k+1
     // from the top (base + size - 1 - J).  In snake order their tile counts add up to the same number
-    // for every wave, so nothing is wasted (NBL = 7, NW = 4: 7 slots per wave instead of 7 + 3).
+    // for every wave, so nothing is wasted (NBL = 7, four tile waves: 7 slots per wave instead of 7 + 3; three: 10).
     static constexpr int pairsize(int k)
     {
         int best = 0;
-        for (int w = 0; w < NW; ++w) {
+        for (int w = 0; w < NWM; ++w) {
             const int a = rowof(2 * k, w) + 1 > 0 ? rowof(2 * k, w) + 1 : 0;
             const int c = (2 * k + 1 < NPOS && rowof(2 * k + 1, w) + 1 > 0) ? rowof(2 * k + 1, w) + 1 : 0;
             best = a + c > best ? a + c : best;
@@ -93,34 +111,96 @@ template <int NBL, int NW> struct TileMat {
         return (p & 1) ? pairbase(p / 2) + pairsize(p / 2) - 1 - J : pairbase(p / 2) + J;
     }
     static constexpr int NSLOT = pairbase((NPOS + 1) / 2);
-    static constexpr int minrow(int p) { return NBL - 1 - p * NW - (NW - 1); }   // smallest row any wave has at position p
     static constexpr int NROW = 16 * NPOS;                                 // matrix rows a wave owns (at most)
     struct Pos {
-        int tid, lane, w, g, c;
+        int tid, lane, w, g, c;      // w: index among the tile-owning waves (-1: the chain wave)
+        bool chain;
         QPX_DEV explicit Pos(const Block& blk)
-            : tid(blk.tid), lane(blk.lane()), w(NW == 1 ? 0 : blk.uniform(blk.wave())), g(blk.lane() >> 4),
-              c(blk.lane() & 15)
+            : tid(blk.tid), lane(blk.lane()), w(NW == 1 ? 0 : blk.uniform(blk.wave()) - (CH ? 1 : 0)), g(blk.lane() >> 4),
+              c(blk.lane() & 15), chain(CH && blk.uniform(blk.wave()) == 0)
         {
         }
+        // Chain-wave form: the role follows the SIMD the wave runs on -- SIMD 0 hosts the chain wave, SIMDs 1 .. 3 the
+        // tile waves -- provided the four waves of this workgroup really sit on four different SIMDs (observed for
+        // every workgroup of every launch on MI355X, profiles/r03a; nothing promises it, so it is checked: each wave
+        // sets its SIMD's bit in an LDS word).  Otherwise, and in the emulation, the role is the wave index.
+        // `word` is an LDS int the caller does not use before its next barrier.
+        QPX_DEV void assign(const Block& blk, int* word)
+        {
+            if constexpr (CH) {
+                const int simd = blk.simd_id();
+                if (blk.tid == 0) *word = 0;
+                blk.sync();
+                if (lane == 0) blk.lds_or(word, 1 << simd);
+                blk.sync();
+                const int mask = *word;
+                blk.sync();
+                if (blk.uniform(mask) == 15) {
+                    chain = simd == 0;
+                    w = simd - 1;
+                }
+            }
+        }
+        // the wave that does the O(m) vector work of the interior-point loop
+        QPX_DEV bool lead(const Block& blk) const { return CH ? chain : blk.wave() == 0; }
+        QPX_DEV bool is_chain() const { return CH && chain; }
+        QPX_DEV int wi() const { return w; }                 // index among the tile waves
+        // the same position with lane coordinates the optimiser cannot trace back (see QPX_LAUNDER_V)
+        QPX_DEV Pos fresh() const
+        {
+            Pos q = *this;
+            QPX_LAUNDER_V(q.lane);
+            QPX_LAUNDER_V(q.g);
+            QPX_LAUNDER_V(q.c);
+            return q;
+        }
         // tile row of position p (< 0: none).  Rows are dealt from the bottom in snake order (w, then
-        // NW-1-w, ...) so that the tile counts of the waves stay close as the factorisation retires rows
-        QPX_DEV int row(int p) const { return NBL - 1 - p * NW - ((p & 1) ? NW - 1 - w : w); }   // = rowof(p, w)
+        // NWM-1-w, ...) so that the tile counts of the waves stay close as the factorisation retires rows
+        QPX_DEV int row(int p) const
+        {
+            if (CH && chain) return -1;
+            return NBL - 1 - p * NWM - ((p & 1) ? NWM - 1 - w : w);      // = rowof(p, w)
+        }
     };
+    // A position whose ROLE is a compile-time constant: -1 = the chain wave, 0 .. NWM-1 = that tile wave -- row(p) is
+    // then a constant and every "does this wave own ..." test in the functions below folds away.  The kernels of the
+    // chain-wave form run their whole body once per role (with_role): with run-time roles the four waves' different
+    // tile sets meet in the same registers behind scalar branches, which cost the factorisation forty 64-bit moves per
+    // panel at the loop's back edge and kept the MFMA chains of different tiles from being interleaved.
+    template <int ROLE> struct RolePos : Pos {
+        QPX_DEV explicit RolePos(const Pos& q) : Pos(q) {}
+        QPX_DEV constexpr int row(int p) const { return ROLE < 0 ? -1 : rowof(p, ROLE < 0 ? 0 : ROLE); }
+        QPX_DEV constexpr bool lead(const Block&) const { return ROLE < 0; }
+        QPX_DEV constexpr bool is_chain() const { return ROLE < 0; }
+        QPX_DEV constexpr int wi() const { return ROLE; }
+        QPX_DEV RolePos fresh() const { return RolePos(Pos::fresh()); }
+    };
+    template <class P> struct role_of { static constexpr int value = -2; };                    // run-time role
+    template <int ROLE> struct role_of<RolePos<ROLE>> { static constexpr int value = ROLE; };
+    // f(position): once with the run-time position, or (chain-wave form) with this wave's role as a constant
+    template <class F> static QPX_DEV void with_role(const Pos& p, F&& f)
+    {
+        if constexpr (CH) {
+            if (p.chain) f(RolePos<-1>(p));
+            else if (p.w == 0) f(RolePos<0>(p));
+            else if (p.w == 1) f(RolePos<1>(p));
+            else f(RolePos<2>(p));
+        } else {
+            f(p);
+        }
+    }
     struct Regs { T e[NSLOT][4]; };
-#ifdef QPX_TILE_PANEL4
-    // scratch: X (2 x 4 x MP) | S (2 x 16) | part (NW x NBL x 64) | red (NW x NROW x 17) | yrow (MP)
-    static constexpr int kX = 0, kS = 8 * MP, kPart = kS + 32, kRed = kPart + NW * NBL * 64, kRow = kRed + NW * NROW * 17;
-#else
     // scratch: X (16 x XS: the 16 old rows of a panel) | S, W (16 x SS: pivot block, its inverse factor) | flag |
-    // { part (NW x NBL x 64) | red (NW x NROW x 17) } or, during a factorisation, BT (NBL x 256: the operand
-    // tiles) | yrow (MP).  XS = 17 mod 32 and SS = 18 keep both the row-wise and the transposed accesses
+    // { part (NWM x NBL x 64) | red (NWM x NROW x 17) } or, during a factorisation, BT (NBL x 256: the operand
+    // tiles; chain-wave form: + AT, the same tiles times -1/d) | yrow (MP) | chain-wave form: S2 (256: the diagonal
+    // tile after next).  XS = 17 mod 32 and SS = 18 keep both the row-wise and the transposed accesses
     // (lane stride XS resp. SS doubles) on distinct LDS banks.
     static constexpr int XS = tile_xs(NBL), SS = 18;
     static constexpr int kX = 0, kS = 16 * XS, kW = kS + 16 * SS, kFlag = kW + 16 * SS, kPart = kFlag + 2;
-    static constexpr int kRed = kPart + NW * NBL * 64, kBT = kPart;
-    static constexpr int kRow = kPart + tile_union(NBL, NW);
-#endif
-    QPX_LAYOUT_HD static size_t scratch_elems() { return (size_t)kRow + MP; }
+    static constexpr int kRed = kPart + NWM * NBL * 64, kBT = kPart, kAT = kBT + NBL * 256;
+    static constexpr int kRow = kPart + (CH ? tile_union_chain(NBL, NWM) : tile_union(NBL, NWM));
+    static constexpr int kS2 = kRow + MP;
+    QPX_LAYOUT_HD static size_t scratch_elems() { return (size_t)kRow + MP + (CH ? 256 : 0); }
     static QPX_DEV void sync(const Block& blk)
     {
         if (NW == 1) blk.wave_sync();
@@ -129,8 +209,9 @@ template <int NBL, int NW> struct TileMat {
     static QPX_DEV const T* image(const T* F, const FacLayout& lay) { return F + lay.Rm; }
 
     // img: tile (I, J), J <= I, at [(I (I + 1) / 2 + J) * 256 + r * 64 + lane]
-    static QPX_DEV void load(const Block& blk, const Pos& p, Regs& E, const T* img)
+    template <class P> static QPX_DEV void load(const Block& blk, const P& p0, Regs& E, const T* img)
     {
+        const P p = p0.fresh();
         const GlobalRows<T> rows(img, NBL * (NBL + 1) / 2 * 256, p.lane);
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
@@ -145,7 +226,7 @@ template <int NBL, int NW> struct TileMat {
         }
     }
 
-    static QPX_DEV void add_diag(const Pos& p, Regs& E, const T* vd)
+    template <class P> static QPX_DEV void add_diag(const P& p, Regs& E, const T* vd)
     {
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
@@ -162,10 +243,10 @@ template <int NBL, int NW> struct TileMat {
 
     // Sums over the 16 columns of every tile row of this wave: acc[pp][r] of lane (g, c) is a partial of
     // matrix row 16 I_pp + g + 4 r.  Through LDS: one padded line of 17 per row, one lane adds a line.
-    template <class F>
-    static QPX_DEV void row_reduce(const Block& blk, const Pos& p, const T (&acc)[NPOS][4], T* scr, F&& emit)
+    template <class P, class F>
+    static QPX_DEV void row_reduce(const Block& blk, const P& p, const T (&acc)[NPOS][4], T* scr, F&& emit)
     {
-        T* red = scr + kRed + p.w * (NROW * 17);
+        T* red = scr + kRed + p.wi() * (NROW * 17);
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp)
 #pragma unroll
@@ -184,7 +265,7 @@ template <int NBL, int NW> struct TileMat {
         }
     }
 
-    // out[j] = +-(base[j] + the column partials of every wave), fixed order
+    // out[j] = +-(base[j] + the column partials of every tile wave), fixed order
     template <bool kNeg>
     static QPX_DEV void gather_cols(const Block& blk, const T* part, const T* base, T* out)
     {
@@ -192,7 +273,7 @@ template <int NBL, int NW> struct TileMat {
             const int J = j >> 4, cc = j & 15;
             T sum = base[j];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
+            for (int w = 0; w < NWM; ++w) {
                 const T* pp = part + (size_t)(w * NBL + J) * 64 + cc;
                 sum += (pp[0] + pp[16]) + (pp[32] + pp[48]);
             }
@@ -201,231 +282,66 @@ template <int NBL, int NW> struct TileMat {
     }
 
     // vout = S vin for the symmetric matrix in E (diagonal tiles hold both triangles)
-    static QPX_DEV void symv(const Block& blk, const Pos& p, const Regs& E, const T* vin, T* vout, T* scr)
+    template <class P> static QPX_DEV void symv(const Block& blk, const P& p0, const Regs& E, const T* vin, T* vout, T* scr)
     {
+        const P p = p0.fresh();
         T* part = scr + kPart;
         T* yrow = scr + kRow;
-        T acc[NPOS][4], u[NPOS][4];
-#pragma unroll
-        for (int pp = 0; pp < NPOS; ++pp) {
-            const int I = p.row(pp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[pp][r] = T(0);
-                u[pp][r] = I >= 0 ? vin[16 * I + p.g + 4 * r] : T(0);
-            }
-        }
-#pragma unroll
-        for (int J = 0; J < NBL; ++J) {
-            const T xj = vin[16 * J + p.c];
-            T col = 0;
+        if (!p.is_chain()) {
+            T acc[NPOS][4], u[NPOS][4];
 #pragma unroll
             for (int pp = 0; pp < NPOS; ++pp) {
-                if (J >= psize(pp)) continue;
                 const int I = p.row(pp);
-                if (J > I) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[pp][r] = fma_(E.e[slot(pp, J)][r], xj, acc[pp][r]);
-                if (J < I) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) col = fma_(E.e[slot(pp, J)][r], u[pp][r], col);
+                for (int r = 0; r < 4; ++r) {
+                    acc[pp][r] = T(0);
+                    u[pp][r] = I >= 0 ? vin[16 * I + p.g + 4 * r] : T(0);
                 }
             }
-            part[(size_t)(p.w * NBL + J) * 64 + p.lane] = col;
+#pragma unroll
+            for (int J = 0; J < NBL; ++J) {
+                const T xj = vin[16 * J + p.c];
+                T col = 0;
+#pragma unroll
+                for (int pp = 0; pp < NPOS; ++pp) {
+                    if (J >= psize(pp)) continue;
+                    const int I = p.row(pp);
+                    if (J > I) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[pp][r] = fma_(E.e[slot(pp, J)][r], xj, acc[pp][r]);
+                    if (J < I) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) col = fma_(E.e[slot(pp, J)][r], u[pp][r], col);
+                    }
+                }
+                part[(size_t)(p.wi() * NBL + J) * 64 + p.lane] = col;
+            }
+            row_reduce(blk, p, acc, scr, [&](int i, T s) { yrow[i] = s; });
         }
-        row_reduce(blk, p, acc, scr, [&](int i, T s) { yrow[i] = s; });
         sync(blk);
         gather_cols<false>(blk, part, yrow, vout);
         sync(blk);
     }
 
-#ifdef QPX_TILE_PANEL4
-    // ---- one panel of ldl_inv: rows/columns k0 .. k0+3, k0 = 16 Ip + 4 SP.  gm[k] = (g == k) as 0/1.
-    template <int SP>
-    static QPX_DEV int panel(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, const T (&gm)[4],
-                             int npos, int nend, long long (&pacc)[8])
-    {
-        QPX_PP(5)
-        const int k0 = 16 * Ip + 4 * SP;
-        T* X = scr + kX + (SP & 1) * 4 * MP;
-        T* S = scr + kS + (SP & 1) * 16;
-        const bool inpan = (p.c >> 2) == SP;
-        const int kc = p.c & 3;
-        // -- publish: the panel's four rows left of the panel (in the panel's own tile only the columns
-        // left of it: the identity and the columns below are written by other lanes further down, and two
-        // lanes must not write one address even if a GPU wave would order them) ...
-#pragma unroll
-        for (int pp = 0; pp < NPOS; ++pp) {
-            if (p.row(pp) != Ip) continue;
-#pragma unroll
-            for (int J = 0; J < psize(pp); ++J)
-                if (J < Ip || (J == Ip && p.c < 4 * SP)) X[p.g * MP + 16 * J + p.c] = E.e[slot(pp, J)][SP];
-        }
-        // ... the pivot block (identity in X, the block itself in S) and the four columns below it.
-        // Row g + 4 r of tile row I lies below the panel iff I > Ip or r > SP.  The panel's own columns
-        // restart from zero: they are published, and the update writes -l~ W into them.
-        if (inpan) {
-#pragma unroll
-            for (int J = 0; J < NBL; ++J) {
-                if (J != Ip) continue;
-#pragma unroll
-                for (int pp = 0; pp < NPOS; ++pp) {
-                    if (J >= psize(pp)) continue;
-                    const int I = p.row(pp);
-                    if (I < Ip) continue;
-                    if (I == Ip) {
-                        S[p.g * 4 + kc] = E.e[slot(pp, J)][SP];
-                        X[p.g * MP + 16 * J + p.c] = (kc == p.g) ? T(1) : T(0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (I > Ip || r > SP) X[kc * MP + 16 * I + p.g + 4 * r] = E.e[slot(pp, J)][r];
-                        E.e[slot(pp, J)][r] = T(0);
-                    }
-                }
-            }
-        }
-        QPX_PP(0)
-        sync(blk);
-        QPX_PP(1)
-        // -- the 4 x 4 pivot block: S = L D L^T, W = L^-1 (unit lower), every lane the same numbers
-        const T s00 = S[0], s10 = S[4], s11 = S[5], s20 = S[8], s21 = S[9], s22 = S[10];
-        const T s30 = S[12], s31 = S[13], s32 = S[14], s33 = S[15];
-        const T d0 = s00, r0 = rcp_(d0);
-        const T l10 = s10 * r0, l20 = s20 * r0, l30 = s30 * r0;
-        const T d1 = fma_(-l10, s10, s11), r1 = rcp_(d1);
-        const T v21 = fma_(-l20, s10, s21), v31 = fma_(-l30, s10, s31);
-        const T l21 = v21 * r1, l31 = v31 * r1;
-        const T d2 = fma_(-l21, v21, fma_(-l20, s20, s22)), r2 = rcp_(d2);
-        const T v32 = fma_(-l31, v21, fma_(-l30, s20, s32));
-        const T l32 = v32 * r2;
-        const T d3 = fma_(-l32, v32, fma_(-l31, v31, fma_(-l30, s30, s33))), r3 = rcp_(d3);
-        // pivots k < npos must be positive, npos <= k < nend negative (the equality block of the
-        // augmented matrix in the pre-factorisation), the rest (identity padding) positive
-        const T big = T(1e300);                  // NaN fails d > 0, +/-inf fails |d| < big
-        const T g0 = (k0 >= npos && k0 < nend) ? -d0 : d0, g1 = (k0 + 1 >= npos && k0 + 1 < nend) ? -d1 : d1;
-        const T g2 = (k0 + 2 >= npos && k0 + 2 < nend) ? -d2 : d2, g3 = (k0 + 3 >= npos && k0 + 3 < nend) ? -d3 : d3;
-        const bool good = (g0 > T(0)) && (g1 > T(0)) && (g2 > T(0)) && (g3 > T(0)) && (g0 < big) && (g1 < big) &&
-                          (g2 < big) && (g3 < big);
-        if (!good) {
-            const bool posok = !(k0 < npos && !(g0 > T(0) && g0 < big)) && !(k0 + 1 < npos && !(g1 > T(0) && g1 < big)) &&
-                               !(k0 + 2 < npos && !(g2 > T(0) && g2 < big)) && !(k0 + 3 < npos && !(g3 > T(0) && g3 < big));
-            return posok ? 2 : 1;               // 1: a pivot that must be positive is not; 2: one that must be negative
-        }
-        const T w10 = -l10, w21 = -l21, w32 = -l32;
-        const T w20 = fma_(l21, l10, -l20);
-        const T w31 = fma_(l32, l21, -l31);
-        const T w30 = fma_(-w32, l20, fma_(-w31, l10, -l30));
-        // row g of W and 1/d_g of this lane's group: sums against the 0/1 group masks (branch-free,
-        // and cheaper than chains of 64-bit selects)
-        const T cg0 = fma_(gm[3], w30, fma_(gm[2], w20, gm[1] * w10));
-        const T cg1 = fma_(gm[3], w31, gm[2] * w21);
-        const T cg2 = gm[3] * w32;
-        const T rg = fma_(gm[3], r3, fma_(gm[2], r2, fma_(gm[1], r1, gm[0] * r0)));
-        if (p.w == 0 && p.c == 0) rd[k0 + p.g] = rg;
-        QPX_PP(2)
-        // -- operands: bop[J] is the B operand of tile column J (the new W~ rows of the panel left of it,
-        // L~_pp^-1 inside it, the un-scaled columns right of it); the A operand of tile row I is the same
-        // combination at position 16 I + c, times -1/d_g, with zeros for rows not below the panel
-        const T* Xg = X + p.g * MP;
-        T bop[NBL];
-#pragma unroll
-        for (int J = 0; J < NBL; ++J) {
-            const int j = 16 * J + p.c;
-            bop[J] = fma_(cg2, X[2 * MP + j], fma_(cg1, X[MP + j], fma_(cg0, X[j], Xg[j])));
-        }
-        const T nrg = -rg;
-        T aop[NPOS];
-#pragma unroll
-        for (int pp = 0; pp < NPOS; ++pp) {
-            const int I = p.row(pp);
-            aop[pp] = T(0);
-            if (I < Ip) continue;
-            const int i = 16 * I + p.c;
-            const T t = fma_(cg2, X[2 * MP + i], fma_(cg1, X[MP + i], fma_(cg0, X[i], Xg[i])));
-            aop[pp] = (I > Ip || p.c > 4 * SP + 3) ? t * nrg : T(0);
-        }
-        QPX_PP(3)
-        // -- the panel's own rows are final: W~ rows left of the panel, L~_pp^-1 inside it.  (The diagonal
-        // entries get the 1 of the unit factor; the d_k live in rd[] as reciprocals, E's diagonal is never
-        // read after the factorisation.)
-#pragma unroll
-        for (int pp = 0; pp < NPOS; ++pp) {
-            if (p.row(pp) != Ip) continue;
-#pragma unroll
-            for (int J = 0; J < psize(pp); ++J)
-                if (J <= Ip) E.e[slot(pp, J)][SP] = bop[J];
-        }
-        // -- rank-4 update of every owned tile at or below the panel's tile row
-#pragma unroll
-        for (int pp = 0; pp < NPOS; ++pp) {
-            const int I = p.row(pp);
-            if (I < Ip) continue;
-#pragma unroll
-            for (int J = 0; J < psize(pp); ++J)
-                if (J <= minrow(pp) || J <= I) blk.mfma16x16x4(aop[pp], bop[J], E.e[slot(pp, J)]);
-        }
-        QPX_PP(4)
-        return 0;
-    }
-
-    // E: symmetric matrix (padded with the identity); eliminates columns 0 .. ncol-1 (rounded up to a
-    // panel): strictly lower part of those columns -> W~ = L~^-1 (rows beyond ncol: -(row block) W~),
-    // trailing block -> Schur complement, rd[k] = 1/d_k.  Pivots k < npos must be positive, npos <= k <
-    // nend negative, others positive.  Uniform return value: 0, or 1 / 2 = a positive / negative pivot
-    // broke down.
-    static QPX_DEV int ldl_inv_signed(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int ncol, int npos, int nend)
-    {
-        const T gm[4] = {p.g == 0 ? T(1) : T(0), p.g == 1 ? T(1) : T(0), p.g == 2 ? T(1) : T(0), p.g == 3 ? T(1) : T(0)};
-        int fail = 0;
-        long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef QPX_PANEL_PROF
-        pacc[7] = clock64();
-#endif
-#pragma unroll 1
-        for (int Ip = 0; Ip < NBL && !fail; ++Ip) {
-            const int k0 = 16 * Ip;
-            if (k0 >= ncol) break;
-            fail = panel<0>(blk, p, E, scr, rd, Ip, gm, npos, nend, pacc);
-            if (!fail && k0 + 4 < ncol) fail = panel<1>(blk, p, E, scr, rd, Ip, gm, npos, nend, pacc);
-            if (!fail && k0 + 8 < ncol) fail = panel<2>(blk, p, E, scr, rd, Ip, gm, npos, nend, pacc);
-            if (!fail && k0 + 12 < ncol) fail = panel<3>(blk, p, E, scr, rd, Ip, gm, npos, nend, pacc);
-        }
-#ifdef QPX_PANEL_PROF
-        if (p.tid == 0) {
-            for (int i = 0; i < 6; ++i) atomicAdd(&qpx_panel_prof[i], (unsigned long long)pacc[i]);
-            atomicAdd(&qpx_panel_prof[6], 1ull);
-        }
-#endif
-        sync(blk);
-        return fail;
-    }
-    // E: T (SPD, order m, padded with the identity) -> strictly lower: W~ = L~^-1, rd[k] = 1/d_k.
-    static QPX_DEV bool ldl_inv(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int m)
-    {
-        return ldl_inv_signed(blk, p, E, scr, rd, m, MP, MP) == 0;
-    }
-
-#else
     // ---- ldl_inv BLOCKED BY SIXTEEN COLUMNS (one tile column per panel, two barriers per panel).
     //
     // Panel Ip = rows/columns 16 Ip .. 16 Ip + 15, pivot block P = E(Ip, Ip) = L~_pp D L~_pp^T, W_pp = L~_pp^-1:
     //   publish   X_J (16 x 16, J = 0 .. NBL-1, J != Ip) = the panel's sixteen "old" rows: the W~ entries E(Ip, J) left
     //             of the panel (from the wave that owns tile row Ip), the panel's columns read down the matrix,
     //             E(J, Ip)^T, right of it (from the owners of those tiles; the update restarts them from zero).
-    //   factor    the owner of tile row Ip moves P to "lane (g, c) = row c, columns 4 g .. 4 g + 3" (through LDS, inside
-    //             the wave) and eliminates it there: per pivot one v_rcp_f64_dpp + Newton, the multipliers copied to
+    //   factor    one wave moves P to "lane (g, c) = row c, columns 4 g .. 4 g + 3" (through LDS) and eliminates it
+    //             there: per pivot one v_rcp_f64_dpp + Newton, the multipliers copied to
     //             the four lane groups by lane swaps, and ONE v_fmac_f64_dpp per register -- the pivot row arrives
     //             through the DPP row broadcast; nothing is published, no barrier.  The same rank-1 update builds W~
-    //             in place of the eliminated columns (as everywhere in this file).  It overlaps with the other
-    //             waves' publish.                                                       -- barrier A --
+    //             in place of the eliminated columns (as everywhere in this file).
     //   operands  b_J = W_pp X_J on the matrix core (4 MFMAs per J, the J dealt over the waves; b_Ip = W_pp), written
-    //             to LDS in the accumulator layout.                                   -- barrier B --
+    //             to LDS in the accumulator layout.
     //   update    E(Ip, J) = b_J (the panel's own rows are final);  E(I, J) += (-D^-1 b_I)^T b_J for I > Ip, J <= I:
     //             register r of b_J is the B operand of k-slice r as it is, and register r of b_I times -1/d is the
     //             A operand (the accumulator layout indexes both by (row g + 4 r, column c)).
-    // Per sixteen columns: 2 barriers (four-column panels: 4), ~30 + 16 x 25 (one wave) vector instructions per
-    // wave around the MFMAs (four-column panels: 4 x 230 in every wave).
+    // Order in time, CH = false (panel16):  publish | factor (the owner of tile row Ip; the others wait) -- barrier A --
+    // operands -- barrier B -- update.  CH = true (ldl_inv_chain): see there.
+    //
     // Pivot K of the 16 x 16 pivot block held as lane (g, c) = row c, columns 4 g .. 4 g + 3 (four registers) plus,
     // in every group, the row's own diagonal entry dg (updated by dg -= l~^2 d, which needs nothing from other
     // lanes): the pivot d_K is then lane K's dg in every group, so its reciprocal (the long chain: estimate + two
@@ -449,18 +365,73 @@ template <int NBL, int NW> struct TileMat {
         }
     }
 
-    static QPX_DEV bool panel16(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, int m, long long (&pacc)[8])
+    // The pivot block in S (LDS, row-major, stride SS) -> its unit-lower inverse factor in W (strictly lower part), the
+    // reciprocals of its pivots in rd[k0 ..], flag[0] = 1 if a pivot is not positive and finite.  One wave; kmax = the
+    // pivots that are not identity padding (>= 16: all; the padded ones are skipped: d = 1, no multipliers, their
+    // columns of W are zero).
+    static QPX_DEV void pivot_block(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax)
     {
-        QPX_PP(5)
-        T* X = scr + kX;
         T* S = scr + kS;
         T* W = scr + kW;
-        T* BT = scr + kBT;
         T* flag = scr + kFlag;
-        const int k0 = 16 * Ip;
-        const int kmax = m - k0;              // pivots of this block that are not identity padding (>= 16: all)
-        bool mine = false;
-        // -- publish
+        T a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
+        T dg = S[p.c * SS + p.c], myr = T(1);
+        pivot16<0>(blk, p, a, dg, myr);
+        if (kmax > 1) pivot16<1>(blk, p, a, dg, myr);
+        if (kmax > 2) pivot16<2>(blk, p, a, dg, myr);
+        if (kmax > 3) pivot16<3>(blk, p, a, dg, myr);
+        if (kmax > 4) pivot16<4>(blk, p, a, dg, myr);
+        if (kmax > 5) pivot16<5>(blk, p, a, dg, myr);
+        if (kmax > 6) pivot16<6>(blk, p, a, dg, myr);
+        if (kmax > 7) pivot16<7>(blk, p, a, dg, myr);
+        if (kmax > 8) pivot16<8>(blk, p, a, dg, myr);
+        if (kmax > 9) pivot16<9>(blk, p, a, dg, myr);
+        if (kmax > 10) pivot16<10>(blk, p, a, dg, myr);
+        if (kmax > 11) pivot16<11>(blk, p, a, dg, myr);
+        if (kmax > 12) pivot16<12>(blk, p, a, dg, myr);
+        if (kmax > 13) pivot16<13>(blk, p, a, dg, myr);
+        if (kmax > 14) pivot16<14>(blk, p, a, dg, myr);
+        if (kmax > 15) pivot16<15>(blk, p, a, dg, myr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = (4 * p.g + j < kmax) ? a[j] : T(0);
+        if (p.lane < 16) rd[k0 + p.lane] = myr;
+        // a pivot that is not positive and finite leaves a reciprocal that is not (negative, NaN from inf - inf or
+        // 0 * inf further down, 0 or inf); nothing above traps, so one test of the sixteen reciprocals replaces
+        // two compares in every pivot's chain
+        const bool bad = blk.any(!(myr > T(0) && myr < T(1e300)));
+        if (p.lane == 0) flag[0] = bad ? T(1) : T(0);
+    }
+
+    // The panel's sixteen old rows -> X (and, with_s, the pivot block itself -> S), from the tiles this wave owns.
+    // Chain-wave form: also the NEXT diagonal tile, E(Ip + 1, Ip + 1) as it stands -> S2 (accumulator layout).
+    static QPX_DEV void publish(const Pos& p, const Regs& E, T* scr, int Ip, bool with_s, bool& mine)
+    {
+        T* X = scr + kX;
+        T* S = scr + kS;
+        if constexpr (CH) {
+            // picked by value, stored once: the same store under ten branches is merged by the compiler into one store
+            // through a pointer into the tile array, and a tile array whose address is taken lives in scratch memory
+            T* S2 = scr + kS2;
+            T d2[4] = {T(0), T(0), T(0), T(0)};
+            bool have = false;
+#pragma unroll
+            for (int pp = 0; pp < NPOS; ++pp) {
+                const int I = p.row(pp);
+#pragma unroll
+                for (int J = 0; J < psize(pp); ++J) {
+                    const bool hit = I == Ip + 1 && J == Ip + 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d2[r] = hit ? E.e[slot(pp, J)][r] : d2[r];
+                    have = have || hit;
+                }
+            }
+            if (have) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S2[r * 64 + p.lane] = d2[r];
+            }
+        }
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
             const int I = p.row(pp);
@@ -474,8 +445,14 @@ template <int NBL, int NW> struct TileMat {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) X[(p.g + 4 * r) * XS + 16 * J + p.c] = E.e[slot(pp, J)][r];
                     } else {
+                        if (with_s) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) S[(p.g + 4 * r) * SS + p.c] = E.e[slot(pp, J)][r];
+                            for (int r = 0; r < 4; ++r) S[(p.g + 4 * r) * SS + p.c] = E.e[slot(pp, J)][r];
+                        }
+                        if constexpr (CH) {      // the panel's own block of X: the identity, so that b_Ip = W_pp X_Ip like every other b_J
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) X[(p.g + 4 * r) * XS + 16 * J + p.c] = (p.g + 4 * r == p.c) ? T(1) : T(0);
+                        }
                     }
                 } else if (J == Ip) {
 #pragma unroll
@@ -483,76 +460,38 @@ template <int NBL, int NW> struct TileMat {
                 }
             }
         }
-        QPX_PP(0)
-        // -- the pivot block, by the wave that owns it.  Pivots of the identity padding are skipped (d = 1, no
-        // multipliers): their columns of W are zero.
-        if (mine) {
-            blk.wave_sync();
-            T a[4];
+    }
+
+    // Operand tile b_J = (I + W_strict) X_J of panel Ip (b_Ip = I + W_strict itself) -> acc; wa = the A operand of W
+    static QPX_DEV void operand_tile(const Block& blk, const Pos& p, const T* scr, int Ip, int J, const T (&wa)[4], T (&acc)[4])
+    {
+        const T* X = scr + kX;
+        const T* W = scr + kW;
+        if (J == Ip) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
-            T dg = S[p.c * SS + p.c], myr = T(1);
-            pivot16<0>(blk, p, a, dg, myr);
-            if (kmax > 1) pivot16<1>(blk, p, a, dg, myr);
-            if (kmax > 2) pivot16<2>(blk, p, a, dg, myr);
-            if (kmax > 3) pivot16<3>(blk, p, a, dg, myr);
-            if (kmax > 4) pivot16<4>(blk, p, a, dg, myr);
-            if (kmax > 5) pivot16<5>(blk, p, a, dg, myr);
-            if (kmax > 6) pivot16<6>(blk, p, a, dg, myr);
-            if (kmax > 7) pivot16<7>(blk, p, a, dg, myr);
-            if (kmax > 8) pivot16<8>(blk, p, a, dg, myr);
-            if (kmax > 9) pivot16<9>(blk, p, a, dg, myr);
-            if (kmax > 10) pivot16<10>(blk, p, a, dg, myr);
-            if (kmax > 11) pivot16<11>(blk, p, a, dg, myr);
-            if (kmax > 12) pivot16<12>(blk, p, a, dg, myr);
-            if (kmax > 13) pivot16<13>(blk, p, a, dg, myr);
-            if (kmax > 14) pivot16<14>(blk, p, a, dg, myr);
-            if (kmax > 15) pivot16<15>(blk, p, a, dg, myr);
+            for (int r = 0; r < 4; ++r) acc[r] = W[(p.g + 4 * r) * SS + p.c] + ((p.g + 4 * r == p.c) ? T(1) : T(0));
+        } else {
+            T bx[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = (4 * p.g + j < kmax) ? a[j] : T(0);
-            if (p.lane < 16) rd[k0 + p.lane] = myr;
-            // a pivot that is not positive and finite leaves a reciprocal that is not (negative, NaN from inf - inf or
-            // 0 * inf further down, 0 or inf); nothing above traps, so one test of the sixteen reciprocals replaces
-            // two compares in every pivot's chain
-            const bool bad = blk.any(!(myr > T(0) && myr < T(1e300)));
-            if (p.lane == 0) flag[0] = bad ? T(1) : T(0);
+            for (int s = 0; s < 4; ++s) acc[s] = bx[s] = X[(p.g + 4 * s) * XS + 16 * J + p.c];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) blk.mfma16x16x4(wa[s], bx[s], acc);
         }
-        QPX_PP(1)
-        sync(blk);
-        QPX_PP(2)
-        const T zr = flag[0];                 // 0 from here on
-        if (zr != T(0)) return false;
-        blk.template prio<0>();               // the matrix-instruction streams yield to the other wave's chains
-        // -- operand tiles: b_J = (I + W_strict) X_J
-        {
-            T wa[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) wa[s] = W[p.c * SS + p.g + 4 * s];
-#pragma unroll
-            for (int jj = 0; jj < (NBL + NW - 1) / NW; ++jj) {
-                const int J = p.w + jj * NW;
-                if (J >= NBL) continue;
-                T acc[4];
-                if (J == Ip) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = W[(p.g + 4 * r) * SS + p.c] + ((p.g + 4 * r == p.c) ? T(1) : T(0));
-                } else {
-                    T bx[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[s] = bx[s] = X[(p.g + 4 * s) * XS + 16 * J + p.c];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) blk.mfma16x16x4(wa[s], bx[s], acc);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) BT[J * 256 + r * 64 + p.lane] = acc[r];
-            }
-        }
-        QPX_PP(3)
-        sync(blk);
-        QPX_PP(4)
-        // -- update
-        T aop[NPOS][4];
-        {
+    }
+
+    // Update phase of panel Ip from the operand tiles in BT: the panel's own rows are final (read straight into the
+    // tile registers: an assignment from registers another path also uses costs round-trip copies of the tile), every
+    // owned tile (I, J), I > Ip, J <= I gets its rank-16 update -- except tile (skip, skip) (chain-wave form: the next
+    // pivot block, which the chain wave brings up to date on its own copy).  zr: a zero the compiler cannot see
+    // through.  Chain-wave form: the A operands come scaled from AT (a wave holds ten tiles there; three tile rows of
+    // operands in registers on top of them is what sent tiles to scratch memory).
+    static QPX_DEV void update(const Block& blk, const Pos& p, Regs& E, const T* scr, const T* rd, int Ip, int skip, T zr)
+    {
+        const T* BT = scr + kBT;
+        const T* AT = scr + kAT;
+        const int k0 = 16 * Ip;
+        T aop[CH ? 1 : NPOS][4];
+        if constexpr (!CH) {
             T nrd[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) nrd[r] = -rd[k0 + p.g + 4 * r];
@@ -566,8 +505,6 @@ template <int NBL, int NW> struct TileMat {
                 for (int r = 0; r < 4; ++r) aop[pp][r] = BT[I * 256 + r * 64 + p.lane] * nrd[r];
             }
         }
-        // the panel's own rows are final: W~ rows left of the panel, L~_pp^-1 inside it -- read straight into the tile
-        // registers (an assignment from registers another path also uses costs round-trip copies of the tile)
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp) {
             if (p.row(pp) != Ip) continue;
@@ -585,7 +522,7 @@ template <int NBL, int NW> struct TileMat {
             for (int pp = 0; pp < NPOS; ++pp) {
                 if (J >= psize(pp)) continue;
                 const int I = p.row(pp);
-                need = need || (I > Ip && J <= I);
+                need = need || (I > Ip && J <= I && !(I == skip && J == skip));
             }
             if (!need) continue;
             T bj[4];
@@ -598,91 +535,419 @@ template <int NBL, int NW> struct TileMat {
             for (int pp = 0; pp < NPOS; ++pp) {
                 if (J >= psize(pp)) continue;
                 const int I = p.row(pp);
-                if (I > Ip && J <= I) {
+                if (I > Ip && J <= I && !(I == skip && J == skip)) {
+                    if constexpr (CH) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) aop[0][r] = AT[I * 256 + r * 64 + p.lane];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) E.e[slot(pp, J)][r] *= keep;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) blk.mfma16x16x4(aop[pp][s], bj[s], E.e[slot(pp, J)]);
+                    for (int s = 0; s < 4; ++s) blk.mfma16x16x4(aop[CH ? 0 : pp][s], bj[s], E.e[slot(pp, J)]);
                 }
             }
         }
+    }
+
+    // Chain-wave form, rows of tile wave W as compile-time constants: the sixteen old rows of panel Ip -> X (with_s: the
+    // pivot block -> S), the identity into the panel's own block of X, and the next diagonal tile -> S2
+    template <int W, int PP>
+    static QPX_DEV void publish_row(const Pos& p, const Regs& E, T* scr, int Ip, bool with_s)
+    {
+        constexpr int I = rowof(PP, W);
+        if constexpr (I >= 0) {
+            T* X = scr + kX;
+            T* S = scr + kS;
+            T* S2 = scr + kS2;
+            if (I == Ip + 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S2[r * 64 + p.lane] = E.e[slot(PP, I)][r];
+            }
+            if (I == Ip) {
+#pragma unroll
+                for (int J = 0; J < I; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[(p.g + 4 * r) * XS + 16 * J + p.c] = E.e[slot(PP, J)][r];
+                if (with_s) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S[(p.g + 4 * r) * SS + p.c] = E.e[slot(PP, I)][r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[(p.g + 4 * r) * XS + 16 * I + p.c] = (p.g + 4 * r == p.c) ? T(1) : T(0);
+            } else if (I > Ip) {
+                // tile (I, Ip), transposed; Ip is a run-time column of this row: picked by value (see publish)
+                T t[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+                for (int J = 0; J < I; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = J == Ip ? E.e[slot(PP, J)][r] : t[r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[p.c * XS + 16 * I + p.g + 4 * r] = t[r];
+            }
+        }
+    }
+    template <int W>
+    static QPX_DEV void publish_rows(const Pos& p, const Regs& E, T* scr, int Ip, bool with_s)
+    {
+        publish_row<W, 0>(p, E, scr, Ip, with_s);
+        if constexpr (NPOS > 1) publish_row<W, 1>(p, E, scr, Ip, with_s);
+        if constexpr (NPOS > 2) publish_row<W, 2>(p, E, scr, Ip, with_s);
+    }
+
+    // Chain-wave form: the update phase with the wave's tile rows as COMPILE-TIME constants (W = index of the tile wave;
+    // the caller switches on it).  The run-time form above puts every tile behind scalar branches of its own: four
+    // dependent MFMAs (95 cycles each) behind a fresh LDS load, ~570 cycles per tile.  Here a tile row is one
+    // straight-line block -- operands loaded up front, the MFMAs of its tiles interleaved (k-slice outermost), 83
+    // cycles per MFMA -- and only the row as a whole, the restart of the panel's own column and the tile the chain wave
+    // has taken over sit behind (scalar) conditions.
+    template <int W, int PP>
+    static QPX_DEV void update_row(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr)
+    {
+        constexpr int I = rowof(PP, W);
+        if constexpr (I >= 0) {
+            const T* BT = scr + kBT;
+            const T* AT = scr + kAT;
+            if (I == Ip) {                       // the panel's own rows are final
+#pragma unroll
+                for (int J = 0; J <= I; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) E.e[slot(PP, J)][r] = BT[J * 256 + r * 64 + p.lane];
+            } else if (I > Ip) {
+                T a[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = AT[I * 256 + r * 64 + p.lane];
+                // off-diagonal tiles, in groups of at most four (registers), then the diagonal one
+                constexpr int G = 4;
+#pragma unroll
+                for (int J0 = 0; J0 < I; J0 += G) {
+                    constexpr int dummy = 0;
+                    T b[G][4];
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        const int J = J0 + j;
+                        if (J >= I) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) b[j][r] = BT[J * 256 + r * 64 + p.lane];
+                        const T keep = J == Ip ? zr : T(1);        // the panel's own column restarts from zero
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) E.e[slot(PP, J)][r] *= keep;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const int J = J0 + j;
+                            if (J >= I) continue;
+                            blk.mfma16x16x4(a[s], b[j][s], E.e[slot(PP, J)]);
+                        }
+                }
+                if (I != skip) {
+                    T b[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] = BT[I * 256 + r * 64 + p.lane];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) blk.mfma16x16x4(a[s], b[s], E.e[slot(PP, I)]);
+                }
+            }
+        }
+    }
+    template <int W>
+    static QPX_DEV void update_rows(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr)
+    {
+        // heaviest row last: its tiles are the ones the publish that follows does not read
+        if constexpr (NPOS > 2) update_row<W, 2>(blk, p, E, scr, Ip, skip, zr);
+        if constexpr (NPOS > 1) update_row<W, 1>(blk, p, E, scr, Ip, skip, zr);
+        update_row<W, 0>(blk, p, E, scr, Ip, skip, zr);
+    }
+
+    // Chain-wave form: two operand tiles b_J = X_J + W_strict X_J at once (J0, J1 run-time; J1 < 0: one), their MFMA
+    // chains interleaved; -> BT and, times -1/d, -> AT
+    static QPX_DEV void operand_pair(const Block& blk, const Pos& p, T* scr, int J0, int J1, const T (&wa)[4], const T (&nrd)[4])
+    {
+        const T* X = scr + kX;
+        T* BT = scr + kBT;
+        T* AT = scr + kAT;
+        const int Jb = J1 < 0 ? J0 : J1;
+        T x0[4], x1[4], c0[4], c1[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            c0[s] = x0[s] = X[(p.g + 4 * s) * XS + 16 * J0 + p.c];
+            c1[s] = x1[s] = X[(p.g + 4 * s) * XS + 16 * Jb + p.c];
+        }
+        QPX_SCHED_FENCE();                      // (the scheduler otherwise runs the two chains one after the other)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            blk.mfma16x16x4(wa[s], x0[s], c0);
+            blk.mfma16x16x4(wa[s], x1[s], c1);
+            QPX_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            BT[J0 * 256 + r * 64 + p.lane] = c0[r];
+            AT[J0 * 256 + r * 64 + p.lane] = nrd[r] * c0[r];
+        }
+        if (J1 >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                BT[J1 * 256 + r * 64 + p.lane] = c1[r];
+                AT[J1 * 256 + r * 64 + p.lane] = nrd[r] * c1[r];
+            }
+        }
+    }
+
+    static QPX_DEV bool panel16(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int Ip, int m, long long (&pacc)[8])
+    {
+        QPX_PP(5)
+        T* W = scr + kW;
+        T* BT = scr + kBT;
+        T* flag = scr + kFlag;
+        const int k0 = 16 * Ip;
+        const int kmax = m - k0;              // pivots of this block that are not identity padding (>= 16: all)
+        bool mine = false;
+        publish(p, E, scr, Ip, true, mine);
+        QPX_PP(0)
+        // -- the pivot block, by the wave that owns it
+        if (mine) {
+            blk.wave_sync();
+            pivot_block(blk, p, scr, rd, k0, kmax);
+        }
+        QPX_PP(1)
+        sync(blk);
+        QPX_PP(2)
+        const T zr = flag[0];                 // 0 from here on
+        if (zr != T(0)) return false;
+        blk.template prio<0>();               // the matrix-instruction streams yield to the other wave's chains
+        // -- operand tiles: b_J = (I + W_strict) X_J
+        {
+            T wa[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wa[s] = W[p.c * SS + p.g + 4 * s];
+#pragma unroll
+            for (int jj = 0; jj < (NBL + NW - 1) / NW; ++jj) {
+                const int J = p.w + jj * NW;
+                if (J >= NBL) continue;
+                T acc[4];
+                operand_tile(blk, p, scr, Ip, J, wa, acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) BT[J * 256 + r * 64 + p.lane] = acc[r];
+            }
+        }
+        QPX_PP(3)
+        sync(blk);
+        QPX_PP(4)
+        update(blk, p, E, scr, rd, Ip, -1, zr);
         blk.template prio<3>();
         return true;
     }
 
+    // ---- CHAIN-WAVE FORM.  Look-ahead by one panel; per panel k two barriers, X and Y:
+    //
+    //             chain wave                                    tile waves (two operand tiles each)
+    //   (after X) b_{k+1} = W_k X_{k+1} -> BT, AT;               b_J = W_k X_J -> BT, -D^-1 b_J -> AT   (J != k+1)
+    //             S = S2 + (-D^-1 b_{k+1})^T b_{k+1}: pivot
+    //             block k+1, up to date
+    //   -- barrier Y --
+    //             PIVOT BLOCK k+1 (S -> W, rd, flag)             the updates of panel k (all but tile (k+1, k+1), whose
+    //                                                            only reader was the pivot block); panel k's own rows; the
+    //                                                            sixteen old rows of panel k+1 -> X, E(k+2, k+2) -> S2
+    //   -- barrier X --
+    //
+    // The serial chain of a factorisation is then  pivot block -> b_{k+1} -> one tile update -> pivot block  inside ONE
+    // wave (~4000 cycles per panel on an idle CU), with the ~9 tile updates per tile wave and panel (~3000 cycles of
+    // MFMAs) beside it instead of behind it.  The chain wave needs from the tile waves only two tiles per panel --
+    // E(k+1, k)^T (part of X) and E(k+1, k+1) (S2) as they stand after panel k-1 -- published one panel ahead.
+    // LDS: every buffer is written in one interval and read in the next, never both in one.
+    // ROLE: -1 = the chain wave, 0 .. NWM-1 = tile wave (its rows are compile-time constants in here: the whole
+    // factorisation exists once per role, selected once -- with the roles told apart by scalar branches inside the
+    // panel loop the register allocator no longer kept the tiles in place across the back edge: forty 64-bit moves per
+    // panel and wave).
+    template <int ROLE>
+    static QPX_DEV bool ldl_inv_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int m)
+    {
+        constexpr bool kChain = ROLE < 0;
+        constexpr int W = kChain ? 0 : ROLE;
+        QPX_LAUNDER_S(m);
+        Pos p = p0.fresh();
+        T* S = scr + kS;
+        T* W_ = scr + kW;
+        T* BT = scr + kBT;
+        T* AT = scr + kAT;
+        T* S2 = scr + kS2;
+        T* flag = scr + kFlag;
+        const int npan = (m + 15) / 16 < NBL ? (m + 15) / 16 : NBL;
+        // -- panel 0: its rows and pivot block -> X, S (and E(1, 1) -> S2); then the pivot block
+        if constexpr (!kChain) publish_rows<W>(p, E, scr, 0, true);
+        blk.sync();
+        if constexpr (kChain) pivot_block(blk, p, scr, rd, 0, m);
+        blk.sync();
+        long long cacc[5] = {0, 0, 0, 0, 0};
+#ifdef QPX_PANEL_PROF
+        cacc[4] = clock64();
+#endif
+#pragma unroll 1
+        for (int k = 0; k < npan; ++k) {
+            const T zr = flag[0];             // 0 unless a pivot broke down
+            if (zr != T(0)) return false;
+            const bool la = k + 1 < npan;     // there is a next pivot block
+            p = p0.fresh();
+            // ---- interval 1: operand tiles; the chain wave brings the next pivot block up to date
+            {
+                T wa[4], nrd[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) wa[s] = W_[p.c * SS + p.g + 4 * s];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nrd[r] = -rd[16 * k + p.g + 4 * r];
+                if constexpr (kChain) {
+                    if (la) {
+                        const T* X = scr + kX;
+                        T acc[4], bx[4], ao[4], sacc[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            acc[s] = bx[s] = X[(p.g + 4 * s) * XS + 16 * (k + 1) + p.c];
+                            sacc[s] = S2[s * 64 + p.lane];
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) blk.mfma16x16x4(wa[s], bx[s], acc);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ao[r] = nrd[r] * acc[r];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) blk.mfma16x16x4(ao[s], acc[s], sacc);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            S[(p.g + 4 * r) * SS + p.c] = sacc[r];
+                            BT[(k + 1) * 256 + r * 64 + p.lane] = acc[r];
+                            AT[(k + 1) * 256 + r * 64 + p.lane] = ao[r];
+                        }
+                    }
+                } else {
+                    // the tile waves share the other operand tiles, two each: entries W and W + NWM of the list of the
+                    // J != k + 1 (the last panel has no k + 1: one more entry, for tile wave 0)
+                    blk.template prio<0>();
+                    constexpr int e0 = W, e1 = W + NWM;
+                    const int J0 = (la && e0 > k) ? e0 + 1 : e0, J1 = (la && e1 > k) ? e1 + 1 : e1;
+                    operand_pair(blk, p, scr, J0, J1 < NBL ? J1 : -1, wa, nrd);
+                    if constexpr (W + 2 * NWM < NBL) {
+                        if (!la) operand_pair(blk, p, scr, W + 2 * NWM, -1, wa, nrd);
+                    }
+                    blk.template prio<3>();
+                }
+            }
+            QPX_CP(0)
+            blk.sync();
+            QPX_CP(1)
+            p = p0.fresh();
+            // ---- interval 2: the chain wave eliminates pivot block k+1, the tile waves stream panel k's updates
+            if constexpr (kChain) {
+                if (la) pivot_block(blk, p, scr, rd, 16 * (k + 1), m - 16 * (k + 1));
+            } else {
+                blk.template prio<0>();
+                update_rows<W>(blk, p, E, scr, k, la ? k + 1 : -1, zr);
+                if (la) publish_rows<W>(p, E, scr, k + 1, false);
+                blk.template prio<3>();
+            }
+            QPX_CP(2)
+            blk.sync();
+            QPX_CP(3)
+        }
+#ifdef QPX_PANEL_PROF
+        if (p0.lane == 0) {
+            const int wv = kChain ? 0 : 1 + W;
+            for (int i = 0; i < 4; ++i) atomicAdd(&qpx_chain_prof[4 * wv + i], (unsigned long long)cacc[i]);
+            if (kChain) atomicAdd(&qpx_chain_prof[16], 1ull);
+        }
+#endif
+        return flag[0] == T(0);
+    }
+    static QPX_DEV bool ldl_inv_chain(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int m)
+    {
+        if (p.chain) return ldl_inv_role<-1>(blk, p, E, scr, rd, m);
+        if (p.w == 0) return ldl_inv_role<0>(blk, p, E, scr, rd, m);
+        if (p.w == 1) return ldl_inv_role<1>(blk, p, E, scr, rd, m);
+        return ldl_inv_role<(NWM > 2 ? 2 : 0)>(blk, p, E, scr, rd, m);
+    }
+
     // E: T (SPD, order m, padded with the identity) -> strictly lower: W~ = L~^-1, rd[k] = 1/d_k; false: a pivot
     // broke down (uniform)
-    static QPX_DEV bool ldl_inv(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int m)
+    template <class P> static QPX_DEV bool ldl_inv(const Block& blk, const P& p, Regs& E, T* scr, T* rd, int m)
     {
         bool ok = true;
         blk.template prio<3>();
-        long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (CH) {
+            if constexpr (role_of<P>::value >= -1) ok = ldl_inv_role<role_of<P>::value>(blk, p, E, scr, rd, m);
+            else ok = ldl_inv_chain(blk, p, E, scr, rd, m);
+        } else {
+            long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef QPX_PANEL_PROF
-        pacc[7] = clock64();
+            pacc[7] = clock64();
 #endif
 #pragma unroll 1
-        for (int Ip = 0; Ip < NBL && ok && 16 * Ip < m; ++Ip) ok = panel16(blk, p, E, scr, rd, Ip, m, pacc);
+            for (int Ip = 0; Ip < NBL && ok && 16 * Ip < m; ++Ip) ok = panel16(blk, p, E, scr, rd, Ip, m, pacc);
 #ifdef QPX_PANEL_PROF
-        if (p.tid == 0) {
-            for (int i = 0; i < 6; ++i) atomicAdd(&qpx_panel_prof[i], (unsigned long long)pacc[i]);
-            atomicAdd(&qpx_panel_prof[6], 1ull);
-        }
+            if (p.tid == 0) {
+                for (int i = 0; i < 6; ++i) atomicAdd(&qpx_panel_prof[i], (unsigned long long)pacc[i]);
+                atomicAdd(&qpx_panel_prof[6], 1ull);
+            }
 #endif
-        sync(blk);
+            sync(blk);
+        }
         return ok;
     }
-#endif
+
     // vout = -T^-1 vin = -W~^T D^-1 W~ vin (W~ unit lower in E, strictly lower part stored)
-    static QPX_DEV void solve_neg(const Block& blk, const Pos& p, const Regs& E, const T* rd, int m, const T* vin,
+    template <class P>
+    static QPX_DEV void solve_neg(const Block& blk, const P& p0, const Regs& E, const T* rd, int m, const T* vin,
                                   T* vout, T* tmp, T* scr)
     {
+        const P p = p0.fresh();
         T* part = scr + kPart;
-        // u = D^-1 W~ vin: sums along tile rows, complete inside the owning wave
-        T acc[NPOS][4];
+        if (!p.is_chain()) {
+            // u = D^-1 W~ vin: sums along tile rows, complete inside the owning wave
+            T acc[NPOS][4];
 #pragma unroll
-        for (int pp = 0; pp < NPOS; ++pp)
+            for (int pp = 0; pp < NPOS; ++pp)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[pp][r] = T(0);
+                for (int r = 0; r < 4; ++r) acc[pp][r] = T(0);
 #pragma unroll
-        for (int J = 0; J < NBL; ++J) {
-            const T xj = vin[16 * J + p.c];
+            for (int J = 0; J < NBL; ++J) {
+                const T xj = vin[16 * J + p.c];
 #pragma unroll
-            for (int pp = 0; pp < NPOS; ++pp) {
-                if (J >= psize(pp)) continue;
-                const int I = p.row(pp);
-                if (J > I) continue;
+                for (int pp = 0; pp < NPOS; ++pp) {
+                    if (J >= psize(pp)) continue;
+                    const int I = p.row(pp);
+                    if (J > I) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const T e = (J < I || p.c < p.g + 4 * r) ? E.e[slot(pp, J)][r] : T(0);
-                    acc[pp][r] = fma_(e, xj, acc[pp][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const T e = (J < I || p.c < p.g + 4 * r) ? E.e[slot(pp, J)][r] : T(0);
+                        acc[pp][r] = fma_(e, xj, acc[pp][r]);
+                    }
                 }
             }
-        }
-        row_reduce(blk, p, acc, scr, [&](int i, T s) { tmp[i] = (i < m) ? (s + vin[i]) * rd[i] : T(0); });
-        blk.wave_sync();      // a wave owns whole tile rows: the u it reads next are the ones it just wrote
-        // x = W~^T u: sums down columns, partial per wave, gathered in a fixed order
-        T u[NPOS][4];
-#pragma unroll
-        for (int pp = 0; pp < NPOS; ++pp) {
-            const int I = p.row(pp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) u[pp][r] = I >= 0 ? tmp[16 * I + p.g + 4 * r] : T(0);
-        }
-#pragma unroll
-        for (int J = 0; J < NBL; ++J) {
-            T col = 0;
+            row_reduce(blk, p, acc, scr, [&](int i, T s) { tmp[i] = (i < m) ? (s + vin[i]) * rd[i] : T(0); });
+            blk.wave_sync();      // a wave owns whole tile rows: the u it reads next are the ones it just wrote
+            // x = W~^T u: sums down columns, partial per wave, gathered in a fixed order
+            T u[NPOS][4];
 #pragma unroll
             for (int pp = 0; pp < NPOS; ++pp) {
-                if (J >= psize(pp)) continue;
                 const int I = p.row(pp);
-                if (J > I) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const T e = (J < I || p.c < p.g + 4 * r) ? E.e[slot(pp, J)][r] : T(0);
-                    col = fma_(e, u[pp][r], col);
-                }
+                for (int r = 0; r < 4; ++r) u[pp][r] = I >= 0 ? tmp[16 * I + p.g + 4 * r] : T(0);
             }
-            part[(size_t)(p.w * NBL + J) * 64 + p.lane] = col;
+#pragma unroll
+            for (int J = 0; J < NBL; ++J) {
+                T col = 0;
+#pragma unroll
+                for (int pp = 0; pp < NPOS; ++pp) {
+                    if (J >= psize(pp)) continue;
+                    const int I = p.row(pp);
+                    if (J > I) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const T e = (J < I || p.c < p.g + 4 * r) ? E.e[slot(pp, J)][r] : T(0);
+                        col = fma_(e, u[pp][r], col);
+                    }
+                }
+                part[(size_t)(p.wi() * NBL + J) * 64 + p.lane] = col;
+            }
         }
         sync(blk);
         gather_cols<true>(blk, part, tmp, vout);
@@ -690,26 +955,26 @@ template <int NBL, int NW> struct TileMat {
     }
 };
 
-QPX_LAYOUT_HD size_t lds_elems_ipm_tile(int nbl, int nw, int n, int q)
+QPX_LAYOUT_HD size_t lds_elems_ipm_tile(int nbl, int nw, int n, int q, bool chain = false)
 {
-    return lds_elems_ipm_loop(16 * (size_t)nbl, tile_scratch_elems(nbl, nw), n, q);
+    return lds_elems_ipm_loop(16 * (size_t)nbl, tile_scratch_elems(nbl, chain ? nw - 1 : nw, chain), n, q);
 }
 
-QPX_LAYOUT_HD size_t lds_elems_kkt_tile(int nbl, int nw, int n, int q)
+QPX_LAYOUT_HD size_t lds_elems_kkt_tile(int nbl, int nw, int n, int q, bool chain = false)
 {
-    return lds_elems_kkt_mat(16 * (size_t)nbl, tile_scratch_elems(nbl, nw), n, q);
+    return lds_elems_kkt_mat(16 * (size_t)nbl, tile_scratch_elems(nbl, chain ? nw - 1 : nw, chain), n, q);
 }
 
-template <int NBL, int NW, bool kBackward>
+template <int NBL, int NW, bool kBackward, bool CH = false>
 QPX_DEV void kkt_tile_body(const Block& b, const KktArgs<double>& a, int qp, double* lds)
 {
-    kkt_mat_body<double, TileMat<NBL, NW>, kBackward>(b, a, qp, lds);
+    kkt_mat_body<double, TileMat<NBL, NW, CH>, kBackward>(b, a, qp, lds);
 }
 
-template <int NBL, int NW, int NS>
+template <int NBL, int NW, int NS, bool CH = false>
 QPX_DEV void ipm_tile_body(const Block& b, const IpmArgs<double>& a, int qp, double* lds)
 {
-    ipm_loop_body<double, TileMat<NBL, NW>, NS>(b, a, qp, lds);
+    ipm_loop_body<double, TileMat<NBL, NW, CH>, NS>(b, a, qp, lds);
 }
 
 }  // namespace qpx

@@ -34,9 +34,23 @@ def main():
     fac = KKTFactors.build(tQ, tG, tA, B)
     out = (ctypes.c_ulonglong * 8)()
     for rep in range(2):
+        if hasattr(lib.dll, "qpx_chain_prof_read"):
+            lib.dll.qpx_chain_prof_read((ctypes.c_ulonglong * 20)())     # reset
         res = fac.ipm(tp, th, tb)
         torch.cuda.synchronize()
         lib.dll.qpx_panel_prof_read(out)
+    if hasattr(lib.dll, "qpx_chain_prof_read"):
+        co = (ctypes.c_ulonglong * 20)()
+        lib.dll.qpx_chain_prof_read(co)
+        cc = np.array(list(co), dtype=np.float64)
+        if cc[16] > 0:
+            npan = (m + 15) // 16
+            print("B=%d n=%d m=%d q=%d chain-wave form: %d factorisations; ticks per PANEL" % (B, n, m, q, cc[16]))
+            print("  %-12s %12s %12s %12s %12s %10s" % ("wave", "interval 1", "wait at Y", "interval 2", "wait at X", "sum"))
+            for w, nm in enumerate(["chain", "tile 0", "tile 1", "tile 2"]):
+                v = cc[4 * w:4 * w + 4] / cc[16] / npan
+                print("  %-12s %12.0f %12.0f %12.0f %12.0f %10.0f" % (nm, v[0], v[1], v[2], v[3], v.sum()))
+            return
     c = np.array(list(out), dtype=np.float64)
     nfac = c[6]
     npan = (m + PANEL - 1) // PANEL

@@ -306,21 +306,21 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
     }
     return QPX_OK;
 }
-template <int NBL, int NW, int NS> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void*)
+template <int NBL, int NW, int NS, bool CH = false> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
         std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         double* base = reinterpret_cast<double*>(lds.data());
-        run_block(64 * NW, [&](const Block& b) { ipm_tile_body<NBL, NW, NS>(b, a, qp, base); });
+        run_block(64 * NW, [&](const Block& b) { ipm_tile_body<NBL, NW, NS, CH>(b, a, qp, base); });
     }
     return QPX_OK;
 }
-template <int NBL, int NW, bool kBw> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void*)
+template <int NBL, int NW, bool kBw, bool CH = false> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
         std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         double* base = reinterpret_cast<double*>(lds.data());
-        run_block(64 * NW, [&](const Block& b) { kkt_tile_body<NBL, NW, kBw>(b, a, qp, base); });
+        run_block(64 * NW, [&](const Block& b) { kkt_tile_body<NBL, NW, kBw, CH>(b, a, qp, base); });
     }
     return QPX_OK;
 }
