@@ -101,7 +101,10 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4; by default the library picks by dtype, size and batch.  Adding 16384 runs the four-wave tile
  * kernels without their chain wave (the round-2 form: every wave owns tile rows and the pivot blocks are not
- * eliminated ahead of the trailing updates) -- kept for same-box A/B.
+ * eliminated ahead of the trailing updates) -- kept for same-box A/B.  Adding 32768 runs the pre-factorisation (f64,
+ * padded tile rows <= 14) as a symmetric sweep on matrix-core tiles (qpx_tsweep.h) instead of the rank-1 sweep on a
+ * 16x16 thread grid: same blob, measured no faster on MI355X (the f64 matrix instruction has no rate advantage over
+ * vector FMAs and the padded tiles cost 40 % more flops), so it is opt-in.
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
  * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
  * synchronisation), 0 = automatic (4 from 64 QPs, 2 from 32); bits 20..27 = initial stagger between the side

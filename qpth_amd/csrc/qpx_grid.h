@@ -242,6 +242,7 @@ template <class T, int GS, int NBL> struct GridMat {
     static QPX_DEV void sync(const Block& blk) { GridPos<GS>::sync(blk); }
     static QPX_DEV const T* image(const T* F, const FacLayout& lay) { return F + (GS == 8 ? lay.Rw : lay.Rg); }
     static QPX_DEV void load(const Block& blk, const Pos&, Regs& E, const T* img) { grid_load<T, GS, NBL>(blk, E.e, img); }
+    template <bool kLeadOnly = false>
     static QPX_DEV void symv(const Block& blk, const Pos& g, const Regs& E, const T* vin, T* vout, T* scratch)
     {
         grid_symv<T, GS, NBL>(blk, g, E.e, vin, vout, scratch + 2 * MP + 4);
@@ -251,6 +252,7 @@ template <class T, int GS, int NBL> struct GridMat {
     {
         return grid_ldl_inv<T, GS, NBL>(blk, g, E.e, scratch, scratch + 2 * MP, rd, m);
     }
+    template <bool kLeadOnly = false>
     static QPX_DEV void solve_neg(const Block& blk, const Pos& g, const Regs& E, const T* rd, int m, const T* vin,
                                   T* vout, T* tmp, T* scratch)
     {
@@ -258,13 +260,13 @@ template <class T, int GS, int NBL> struct GridMat {
     }
 };
 
-// LDS elements of the loop kernel: 19 vectors of v = align4(max(n, MP, q)), 16 scalars + 8 control
+// LDS elements of the loop kernel: 20 vectors of v = align4(max(n, MP, q)), 16 scalars + 8 control
 // words, scratch
 QPX_LAYOUT_HD size_t lds_elems_ipm_loop(size_t mp, size_t scratch, int n, int q)
 {
     const size_t d = max2(max2((size_t)n, mp), (size_t)q);
     const size_t v = d <= 64 ? 64 : (d <= 128 ? 128 : (d <= 256 ? 256 : 512));    // 64 NS, see ipm_loop_body
-    return 19 * v + 24 + scratch;
+    return 20 * v + 24 + scratch;
 }
 QPX_LAYOUT_HD size_t lds_elems_ipm_grid(int gs, int nbl, int n, int q)
 {
@@ -328,6 +330,88 @@ QPX_DEV void block_matvec(const Block& blk, T* out, const T* Mat, const T* vec, 
                 if (r0 + u < rows)
                     out[r0 + u] = MODE == 0 ? (T)acc[u] : (MODE == 1 ? (T)((Acc)out[r0 + u] + acc[u]) : (T)((Acc)out[r0 + u] - acc[u]));
         }
+    }
+}
+
+// The same row dots on tiles of 16 rows: lane (g, c) of a wave takes rows r0 + g + 4 r (r = 0 .. 3) and the columns
+// c, c + 16, ... -- 16 lanes read 128 consecutive bytes of a row, sixteen independent loads in flight per lane -- and the
+// sums over a row's sixteen lanes are four DPP steps per register instead of one wave reduction per row (the
+// round-2 form above spent most of its time in those: the loop kernel's epilogue, 25 000 cycles per QP).
+template <class T, int MODE /*0: =, 1: +=, 2: -=*/, class Acc = T>
+QPX_DEV void block_matvec16(const Block& blk, T* out, const T* Mat, const T* vec, int rows, int cols)
+{
+    const int lane = blk.lane(), g = lane >> 4, c = lane & 15, w = blk.uniform(blk.wave()), nw = blk.nwaves();
+    for (int r0 = 16 * w; r0 < rows; r0 += 16 * nw) {
+        Acc acc[4] = {Acc(0), Acc(0), Acc(0), Acc(0)};
+        const T* rowp[4];
+        bool live[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + g + 4 * r;
+            live[r] = row < rows;
+            rowp[r] = Mat + (size_t)(live[r] ? row : rows - 1) * cols;       // clamped: loads stay unconditional
+        }
+        for (int c0 = 0; c0 < cols; c0 += 64) {
+            T mv[4][4];
+            Acc xv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = c0 + 16 * j + c;
+                const bool in = col < cols;
+                xv[j] = in ? (Acc)vec[col] : Acc(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mv[j][r] = rowp[r][in ? col : cols - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fma_((Acc)mv[j][r], xv[j], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Acc v = acc[r];
+            v += blk.template xor16<1>(v);
+            v += blk.template xor16<2>(v);
+            v += blk.template xor16<7>(v);
+            v += blk.template xor16<15>(v);
+            if (c == 0 && live[r]) {
+                const int row = r0 + g + 4 * r;
+                out[row] = MODE == 0 ? (T)v : (MODE == 1 ? (T)((Acc)out[row] + v) : (T)((Acc)out[row] - v));
+            }
+        }
+    }
+}
+
+// Two column-parallel products with one vector at once: outA[c] (opA)= sum_r MatA[r][c] vec[r] (c < colsA) and
+// outB[c] (opB)= sum_r MatB[r][c] vec[r] (c < colsB): the columns of both matrices are dealt over ALL threads (one
+// product alone keeps 100 of 256 threads busy at C2) and sixteen loads are in flight per thread.
+template <class T, int MODEA, int MODEB, class Acc = T>
+QPX_DEV void block_matTvec2(const Block& blk, T* outA, const T* MatA, int colsA, T* outB, const T* MatB, int colsB,
+                            const T* vec, int rows)
+{
+    const int colsAP = (colsA + 63) & ~63;                      // B's columns start at a wave boundary
+    for (int cc = blk.tid; cc < colsAP + colsB; cc += blk.nt) {
+        const bool isA = cc < colsAP;
+        const int c = isA ? cc : cc - colsAP, cols = isA ? colsA : colsB;
+        if (isA && c >= colsA) continue;
+        const T* col = (isA ? MatA : MatB) + c;
+        Acc a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = Acc(0);
+        int r = 0;
+        for (; r + 16 <= rows; r += 16) {
+            T mv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) mv[u] = col[(size_t)(r + u) * cols];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] = fma_((Acc)mv[u], (Acc)vec[r + u], a[u]);
+        }
+        for (; r < rows; ++r) a[0] = fma_((Acc)col[(size_t)r * cols], (Acc)vec[r], a[0]);
+        const Acc sum = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+                        (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+        T* o = (isA ? outA : outB) + c;
+        const int mode = isA ? MODEA : MODEB;
+        *o = mode == 0 ? (T)sum : (mode == 1 ? (T)((Acc)*o + sum) : (T)((Acc)*o - sum));
     }
 }
 
@@ -570,7 +654,8 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
     T* vDZA = vRS + v;    // affine step, corrector right-hand side rs
     T* vDSA = vDZA + v;
     T* vRSC = vDSA + v;
-    T* sc = vRSC + v;                               // 16 scalars of the IPM state
+    T* vX0 = vRSC + v;    // x0 = -K p (n): formed with c at the start, while p's products share their loads' flight
+    T* sc = vX0 + v;                                // 16 scalars of the IPM state
     int* ctrl = reinterpret_cast<int*>(sc + 16);    // 8 elements of control words
     T* scr = sc + 24;     // Mat::scratch_elems()
 
@@ -605,7 +690,7 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         vRH[i] = T(0);
     }
     Mat::sync(b);
-    block_matTvec<T, 1>(b, vC, F + lay.MT, vP, n, m);
+    block_matTvec2<T, 1, 0>(b, vC, F + lay.MT, m, vX0, F + lay.Kneg, n, vP, n);      // c += M p;  x0 = -K p
     if (q > 0) {
         Mat::sync(b);
         for (int i = b.tid; i < q; i += NT) vTm[i] = bg[i];
@@ -641,14 +726,15 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
     // ---- pass -1 is the start point: T = R + I, z_i = -T^-1 c, s_i = -z_i, shifts (batch.py:61-87),
     // and R 1 on the way; passes 0.. are the IPM iterations.  One loop so that the factorisation and
     // the solves are instantiated once (they are the bulk of the kernel's code).
-    // (Re-loading R right after the last solve of the previous pass, so that the loads fly during wave 0's vector
-    // work, was measured: no gain -- profiles/r02b_panel_ab.txt, "late".)
+    // (Re-loading R right after the last solve of the previous pass, so that the loads fly during the lead wave's
+    // vector work, was measured twice: no gain in round 2 -- profiles/r02b_panel_ab.txt, "late" -- and +3 % loop time
+    // with the chain-wave form, profiles/r03h_ab_loop_variants.txt.)
     int stop = 0;
     for (int it = -1; it < a.maxIter && !stop; ++it) {
         const bool first = it < 0;
         Mat::load(b, g, E, Rg);
         QPX_PROF(2)
-        Mat::symv(b, g, E, vA, first ? vR1 : vB, scr);       // first pass: vA = 1
+        Mat::template symv<true>(b, g, E, vA, first ? vR1 : vB, scr);       // first pass: vA = 1; read by the lead wave only
         QPX_PROF(3)
         if (w0 && !first) {
             const T tsz = sc[kTau] * sc[kSigz];
@@ -731,7 +817,7 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         }
         // first pass: z_i = -T^-1 c; iterations: affine scaling direction dz_aff = -T^-1 (c + R z)
         QPX_PROF(1)
-        Mat::solve_neg(b, g, E, rd, m, first ? vC : vRH, vX, vTm, scr);
+        Mat::template solve_neg<true>(b, g, E, rd, m, first ? vC : vRH, vX, vTm, scr);
         QPX_PROF(6)
         if (first) {
             if (w0) {
@@ -809,7 +895,7 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         }
         Mat::sync(b);
         QPX_PROF(1)
-        Mat::solve_neg(b, g, E, rd, m, vRH, vX, vTm, scr);
+        Mat::template solve_neg<true>(b, g, E, rd, m, vRH, vX, vTm, scr);
         QPX_PROF(6)
         if (w0) {
             T z[NS], s[NS], rz[NS], rsv[NS], dz[NS], ds[NS];
@@ -873,9 +959,9 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         for (int i = b.tid; i < q; i += NT) vTm[i] = bg[i];
     Mat::sync(b);
     // zhat = x0 - M^T z' = -K p + N b - M^T z'
-    block_matTvec<T, 0>(b, vX, F + lay.Kneg, vP, n, n);
+    for (int i = b.tid; i < n; i += NT) vX[i] = vX0[i];
     Mat::sync(b);
-    block_matvec<T, 2>(b, vX, F + lay.MT, vA, n, m);
+    block_matvec16<T, 2>(b, vX, F + lay.MT, vA, n, m);
     if (q > 0) {
         Mat::sync(b);
         block_matTvec<T, 2>(b, vX, F + lay.NTn, vTm, q, n);
@@ -995,7 +1081,7 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
         // oX = Kneg rX - M^T oZ + NTn^T rY     (Kneg = -K, NTn = -N^T)
         block_matTvec<T, 0>(b, oX, F + lay.Kneg, rX, n, n);
         Mat::sync(b);
-        block_matvec<T, 2>(b, oX, F + lay.MT, oZ, n, m);
+        block_matvec16<T, 2>(b, oX, F + lay.MT, oZ, n, m);
         if (q > 0) {
             Mat::sync(b);
             block_matTvec<T, 1>(b, oX, F + lay.NTn, rY, q, n);

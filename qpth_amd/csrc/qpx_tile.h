@@ -32,6 +32,8 @@
 // vector FMAs on the same registers; sums along tile rows and down tile columns go through LDS
 // partials that are added in a fixed order (deterministic results).
 #pragma once
+#include <type_traits>
+
 #include "qpx_grid.h"
 
 // Sub-phase timers of one panel (-DQPX_PANEL_PROF, scripts/prof_panel.py): thread 0 of every QP adds the
@@ -62,6 +64,16 @@ static __device__ unsigned long long qpx_chain_prof[20];
 
 namespace qpx {
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a compile-time constant
+template <int I0, int N, class F> QPX_DEV void static_for_(F&& f)
+{
+    if constexpr (I0 < N) {
+        f(std::integral_constant<int, I0>{});
+        static_for_<I0 + 1, N>(f);
+    }
+}
+template <int N, class F> QPX_DEV void static_for(F&& f) { static_for_<0, N>(f); }
+
 // row stride of the panel's X rows (17 mod 32 doubles) and size of the region the mat-vec partials share with the
 // operand tiles of the factorisation (nwm = the waves that own tiles)
 QPX_LAYOUT_HD constexpr int tile_xs(int nbl) { return ((16 * nbl - 17 + 31) / 32) * 32 + 17; }
@@ -82,7 +94,7 @@ QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nwm, bool chain =
 
 template <int NBL, int NW, bool CH = false> struct TileMat {
     using T = double;
-    static_assert(!CH || NW == 4, "the chain-wave form is one chain wave + three tile waves");
+    static_assert(!CH || NW == 4 || NW == 8, "the chain-wave form is one chain wave + three (loop, backward) or seven (tile sweep) tile waves");
     static constexpr int NWM = CH ? NW - 1 : NW;                           // waves that own tiles
     static constexpr int NPOS = (NBL + NWM - 1) / NWM, NT = 64 * NW, MP = 16 * NBL;
     static constexpr int psize(int p) { return NBL - p * NWM; }           // tiles of position p at most (over the waves)
@@ -127,7 +139,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         // `word` is an LDS int the caller does not use before its next barrier.
         QPX_DEV void assign(const Block& blk, int* word)
         {
-            if constexpr (CH) {
+            if constexpr (CH && NW == 4) {
                 const int simd = blk.simd_id();
                 if (blk.tid == 0) *word = 0;
                 blk.sync();
@@ -178,13 +190,20 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     template <class P> struct role_of { static constexpr int value = -2; };                    // run-time role
     template <int ROLE> struct role_of<RolePos<ROLE>> { static constexpr int value = ROLE; };
     // f(position): once with the run-time position, or (chain-wave form) with this wave's role as a constant
+    template <int R, class F> static QPX_DEV void with_tile_role(const Pos& p, F&& f)
+    {
+        if constexpr (R + 1 < NWM) {
+            if (p.w == R) f(RolePos<R>(p));
+            else with_tile_role<R + 1>(p, f);
+        } else {
+            f(RolePos<R>(p));
+        }
+    }
     template <class F> static QPX_DEV void with_role(const Pos& p, F&& f)
     {
         if constexpr (CH) {
             if (p.chain) f(RolePos<-1>(p));
-            else if (p.w == 0) f(RolePos<0>(p));
-            else if (p.w == 1) f(RolePos<1>(p));
-            else f(RolePos<2>(p));
+            else with_tile_role<0>(p, f);
         } else {
             f(p);
         }
@@ -281,8 +300,28 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         }
     }
 
-    // vout = S vin for the symmetric matrix in E (diagonal tiles hold both triangles)
-    template <class P> static QPX_DEV void symv(const Block& blk, const P& p0, const Regs& E, const T* vin, T* vout, T* scr)
+    // the same by one wave (the chain wave, when it is the only consumer of the result: no barrier behind it)
+    template <bool kNeg>
+    static QPX_DEV void gather_cols_wave(const Block& blk, int lane, const T* part, const T* base, T* out)
+    {
+        for (int j = lane; j < MP; j += kWave) {
+            const int J = j >> 4, cc = j & 15;
+            T sum = base[j];
+#pragma unroll
+            for (int w = 0; w < NWM; ++w) {
+                const T* pp = part + (size_t)(w * NBL + J) * 64 + cc;
+                sum += (pp[0] + pp[16]) + (pp[32] + pp[48]);
+            }
+            out[j] = kNeg ? -sum : sum;
+        }
+        blk.wave_sync();
+    }
+
+    // vout = S vin for the symmetric matrix in E (diagonal tiles hold both triangles).  kLeadOnly: only the lead wave
+    // reads vout, and not before the workgroup's next barrier is anything in scr written again (chain-wave form: the
+    // chain wave gathers by itself, one barrier less).
+    template <bool kLeadOnly = false, class P>
+    static QPX_DEV void symv(const Block& blk, const P& p0, const Regs& E, const T* vin, T* vout, T* scr)
     {
         const P p = p0.fresh();
         T* part = scr + kPart;
@@ -319,8 +358,12 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             row_reduce(blk, p, acc, scr, [&](int i, T s) { yrow[i] = s; });
         }
         sync(blk);
-        gather_cols<false>(blk, part, yrow, vout);
-        sync(blk);
+        if constexpr (kLeadOnly && CH && role_of<P>::value >= -1) {
+            if constexpr (role_of<P>::value == -1) gather_cols_wave<false>(blk, p.lane, part, yrow, vout);
+        } else {
+            gather_cols<false>(blk, part, yrow, vout);
+            sync(blk);
+        }
     }
 
     // ---- ldl_inv BLOCKED BY SIXTEEN COLUMNS (one tile column per panel, two barriers per panel).
@@ -359,7 +402,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             const T nl = -(v * r);                               // -l~
             blk.template row_rank1<K>(a, nl);
             a[KK] = p.g == GK ? nl : a[KK];                      // column K: assigned (see qpx_grid.h); 0 on and above the diagonal
-            dg = fma_(nl, v, dg);
+            dg = fma_(nl, v, dg);                                // (moved in front of the rank-1 update: +1 % loop time, r03h)
         } else {
             a[KK] = p.g == GK ? T(0) : a[KK];
         }
@@ -369,7 +412,9 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // reciprocals of its pivots in rd[k0 ..], flag[0] = 1 if a pivot is not positive and finite.  One wave; kmax = the
     // pivots that are not identity padding (>= 16: all; the padded ones are skipped: d = 1, no multipliers, their
     // columns of W are zero).
-    static QPX_DEV void pivot_block(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax)
+    // sign: +1 / -1 = the pivots of this block must all be positive / negative (the equality block of the tile sweep);
+    // flag[0] = 1 / 2 when one is not.
+    static QPX_DEV void pivot_block(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax, int sign = 1)
     {
         T* S = scr + kS;
         T* W = scr + kW;
@@ -400,8 +445,9 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         // a pivot that is not positive and finite leaves a reciprocal that is not (negative, NaN from inf - inf or
         // 0 * inf further down, 0 or inf); nothing above traps, so one test of the sixteen reciprocals replaces
         // two compares in every pivot's chain
-        const bool bad = blk.any(!(myr > T(0) && myr < T(1e300)));
-        if (p.lane == 0) flag[0] = bad ? T(1) : T(0);
+        const T sr = sign > 0 ? myr : ((p.lane < 16 && p.lane < kmax) ? -myr : myr);     // (skipped pivots keep myr = 1)
+        const bool bad = blk.any(!(sr > T(0) && sr < T(1e300)));
+        if (p.lane == 0) flag[0] = bad ? (sign > 0 ? T(1) : T(2)) : T(0);
     }
 
     // The panel's sixteen old rows -> X (and, with_s, the pivot block itself -> S), from the tiles this wave owns.
@@ -600,24 +646,27 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // straight-line block -- operands loaded up front, the MFMAs of its tiles interleaved (k-slice outermost), 83
     // cycles per MFMA -- and only the row as a whole, the restart of the panel's own column and the tile the chain wave
     // has taken over sit behind (scalar) conditions.
-    template <int W, int PP>
+    // kSweep (tile sweep, qpx_tsweep.h): the symmetric sweep instead of the elimination -- EVERY tile row gets the
+    // update (rows above the panel accumulate the negated inverse of the swept block), the panel's own row becomes
+    // (-D^-1 b_Ip)^T b_J instead of b_J.
+    template <int W, int PP, bool kSweep>
     static QPX_DEV void update_row(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr)
     {
         constexpr int I = rowof(PP, W);
         if constexpr (I >= 0) {
             const T* BT = scr + kBT;
             const T* AT = scr + kAT;
-            if (I == Ip) {                       // the panel's own rows are final
+            if (I == Ip && !kSweep) {            // the panel's own rows are final
 #pragma unroll
                 for (int J = 0; J <= I; ++J)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) E.e[slot(PP, J)][r] = BT[J * 256 + r * 64 + p.lane];
-            } else if (I > Ip) {
+            } else if (I > Ip || kSweep) {
                 T a[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] = AT[I * 256 + r * 64 + p.lane];
                 // off-diagonal tiles, in groups of at most four (registers), then the diagonal one
-                constexpr int G = 4;
+                constexpr int G = NSLOT > 12 ? 2 : 4;          // (interleaved MFMA chains per group: registers)
 #pragma unroll
                 for (int J0 = 0; J0 < I; J0 += G) {
                     constexpr int dummy = 0;
@@ -628,7 +677,8 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                         if (J >= I) continue;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) b[j][r] = BT[J * 256 + r * 64 + p.lane];
-                        const T keep = J == Ip ? zr : T(1);        // the panel's own column restarts from zero
+                        // the panel's own column (and, sweep, its own row) restarts from zero
+                        const T keep = (J == Ip || (kSweep && I == Ip)) ? zr : T(1);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) E.e[slot(PP, J)][r] *= keep;
                     }
@@ -645,19 +695,24 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                     T b[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) b[r] = BT[I * 256 + r * 64 + p.lane];
+                    if (kSweep) {
+                        const T keep = I == Ip ? zr : T(1);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) E.e[slot(PP, I)][r] *= keep;
+                    }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) blk.mfma16x16x4(a[s], b[s], E.e[slot(PP, I)]);
                 }
             }
         }
     }
-    template <int W>
+    template <int W, bool kSweep = false>
     static QPX_DEV void update_rows(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr)
     {
         // heaviest row last: its tiles are the ones the publish that follows does not read
-        if constexpr (NPOS > 2) update_row<W, 2>(blk, p, E, scr, Ip, skip, zr);
-        if constexpr (NPOS > 1) update_row<W, 1>(blk, p, E, scr, Ip, skip, zr);
-        update_row<W, 0>(blk, p, E, scr, Ip, skip, zr);
+        if constexpr (NPOS > 2) update_row<W, 2, kSweep>(blk, p, E, scr, Ip, skip, zr);
+        if constexpr (NPOS > 1) update_row<W, 1, kSweep>(blk, p, E, scr, Ip, skip, zr);
+        update_row<W, 0, kSweep>(blk, p, E, scr, Ip, skip, zr);
     }
 
     // Chain-wave form: two operand tiles b_J = X_J + W_strict X_J at once (J0, J1 run-time; J1 < 0: one), their MFMA
@@ -761,12 +816,14 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // factorisation exists once per role, selected once -- with the roles told apart by scalar branches inside the
     // panel loop the register allocator no longer kept the tiles in place across the back edge: forty 64-bit moves per
     // panel and wave).
-    template <int ROLE>
-    static QPX_DEV bool ldl_inv_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int m)
+    // `panel(k)` = (pivots of panel k that are not identity padding, +1 / -1: their sign); npan panels.  kSweep: the
+    // symmetric sweep of the first npan tile rows (update_row).  Returns 0, or the flag of the pivot block that failed.
+    template <int ROLE, bool kSweep, class PanelInfo>
+    static QPX_DEV int factor_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, PanelInfo&& panel)
     {
         constexpr bool kChain = ROLE < 0;
         constexpr int W = kChain ? 0 : ROLE;
-        QPX_LAUNDER_S(m);
+        QPX_LAUNDER_S(npan);
         Pos p = p0.fresh();
         T* S = scr + kS;
         T* W_ = scr + kW;
@@ -774,11 +831,10 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         T* AT = scr + kAT;
         T* S2 = scr + kS2;
         T* flag = scr + kFlag;
-        const int npan = (m + 15) / 16 < NBL ? (m + 15) / 16 : NBL;
         // -- panel 0: its rows and pivot block -> X, S (and E(1, 1) -> S2); then the pivot block
         if constexpr (!kChain) publish_rows<W>(p, E, scr, 0, true);
         blk.sync();
-        if constexpr (kChain) pivot_block(blk, p, scr, rd, 0, m);
+        if constexpr (kChain) pivot_block(blk, p, scr, rd, 0, panel(0).kmax, panel(0).sign);
         blk.sync();
         long long cacc[5] = {0, 0, 0, 0, 0};
 #ifdef QPX_PANEL_PROF
@@ -787,7 +843,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #pragma unroll 1
         for (int k = 0; k < npan; ++k) {
             const T zr = flag[0];             // 0 unless a pivot broke down
-            if (zr != T(0)) return false;
+            if (zr != T(0)) return (int)zr;
             const bool la = k + 1 < npan;     // there is a next pivot block
             p = p0.fresh();
             // ---- interval 1: operand tiles; the chain wave brings the next pivot block up to date
@@ -799,6 +855,8 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                 for (int r = 0; r < 4; ++r) nrd[r] = -rd[16 * k + p.g + 4 * r];
                 if constexpr (kChain) {
                     if (la) {
+                        // (two accumulators per product -- chains of two dependent MFMAs instead of four -- measured no
+                        // gain: this interval waits for the tile waves' operand tiles anyway, profiles/r03h)
                         const T* X = scr + kX;
                         T acc[4], bx[4], ao[4], sacc[4];
 #pragma unroll
@@ -826,8 +884,11 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                     constexpr int e0 = W, e1 = W + NWM;
                     const int J0 = (la && e0 > k) ? e0 + 1 : e0, J1 = (la && e1 > k) ? e1 + 1 : e1;
                     operand_pair(blk, p, scr, J0, J1 < NBL ? J1 : -1, wa, nrd);
-                    if constexpr (W + 2 * NWM < NBL) {
-                        if (!la) operand_pair(blk, p, scr, W + 2 * NWM, -1, wa, nrd);
+                    // (entries beyond the first two per wave: NBL > 2 NWM, or the last panel's one extra entry)
+#pragma unroll
+                    for (int e2 = W + 2 * NWM; e2 < NBL; e2 += NWM) {
+                        const int J2 = (la && e2 > k) ? e2 + 1 : e2;
+                        if (J2 < NBL) operand_pair(blk, p, scr, J2, -1, wa, nrd);
                     }
                     blk.template prio<3>();
                 }
@@ -838,10 +899,10 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             p = p0.fresh();
             // ---- interval 2: the chain wave eliminates pivot block k+1, the tile waves stream panel k's updates
             if constexpr (kChain) {
-                if (la) pivot_block(blk, p, scr, rd, 16 * (k + 1), m - 16 * (k + 1));
+                if (la) pivot_block(blk, p, scr, rd, 16 * (k + 1), panel(k + 1).kmax, panel(k + 1).sign);
             } else {
                 blk.template prio<0>();
-                update_rows<W>(blk, p, E, scr, k, la ? k + 1 : -1, zr);
+                update_rows<W, kSweep>(blk, p, E, scr, k, la ? k + 1 : -1, zr);
                 if (la) publish_rows<W>(p, E, scr, k + 1, false);
                 blk.template prio<3>();
             }
@@ -852,18 +913,19 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #ifdef QPX_PANEL_PROF
         if (p0.lane == 0) {
             const int wv = kChain ? 0 : 1 + W;
-            for (int i = 0; i < 4; ++i) atomicAdd(&qpx_chain_prof[4 * wv + i], (unsigned long long)cacc[i]);
+            if (wv < 4)
+                for (int i = 0; i < 4; ++i) atomicAdd(&qpx_chain_prof[4 * wv + i], (unsigned long long)cacc[i]);
             if (kChain) atomicAdd(&qpx_chain_prof[16], 1ull);
         }
 #endif
-        return flag[0] == T(0);
+        return (int)flag[0];
     }
-    static QPX_DEV bool ldl_inv_chain(const Block& blk, const Pos& p, Regs& E, T* scr, T* rd, int m)
+    struct PanelOf { int kmax, sign; };
+    template <int ROLE>
+    static QPX_DEV bool ldl_inv_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int m)
     {
-        if (p.chain) return ldl_inv_role<-1>(blk, p, E, scr, rd, m);
-        if (p.w == 0) return ldl_inv_role<0>(blk, p, E, scr, rd, m);
-        if (p.w == 1) return ldl_inv_role<1>(blk, p, E, scr, rd, m);
-        return ldl_inv_role<(NWM > 2 ? 2 : 0)>(blk, p, E, scr, rd, m);
+        const int npan = (m + 15) / 16 < NBL ? (m + 15) / 16 : NBL;
+        return factor_role<ROLE, false>(blk, p0, E, scr, rd, npan, [m](int k) { return PanelOf{m - 16 * k, 1}; }) == 0;
     }
 
     // E: T (SPD, order m, padded with the identity) -> strictly lower: W~ = L~^-1, rd[k] = 1/d_k; false: a pivot
@@ -873,8 +935,8 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         bool ok = true;
         blk.template prio<3>();
         if constexpr (CH) {
-            if constexpr (role_of<P>::value >= -1) ok = ldl_inv_role<role_of<P>::value>(blk, p, E, scr, rd, m);
-            else ok = ldl_inv_chain(blk, p, E, scr, rd, m);
+            static_assert(role_of<P>::value >= -1, "chain-wave form: call through with_role");
+            ok = ldl_inv_role<role_of<P>::value>(blk, p, E, scr, rd, m);
         } else {
             long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef QPX_PANEL_PROF
@@ -894,7 +956,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     }
 
     // vout = -T^-1 vin = -W~^T D^-1 W~ vin (W~ unit lower in E, strictly lower part stored)
-    template <class P>
+    template <bool kLeadOnly = false, class P>
     static QPX_DEV void solve_neg(const Block& blk, const P& p0, const Regs& E, const T* rd, int m, const T* vin,
                                   T* vout, T* tmp, T* scr)
     {
@@ -950,8 +1012,12 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             }
         }
         sync(blk);
-        gather_cols<true>(blk, part, tmp, vout);
-        sync(blk);
+        if constexpr (kLeadOnly && CH && role_of<P>::value >= -1) {
+            if constexpr (role_of<P>::value == -1) gather_cols_wave<true>(blk, p.lane, part, tmp, vout);
+        } else {
+            gather_cols<true>(blk, part, tmp, vout);
+            sync(blk);
+        }
     }
 };
 

@@ -214,6 +214,48 @@ def test_every_loop_kernel_form(variant, shape):
             assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
+# Round 3: the chain-wave form of the four-wave tile kernels (the default for 65 <= nineq <= 112), its run-time role
+# assignment (which wave is the chain wave follows the SIMD a wave lands on: QPX_EMU_SIMD_ROT rotates that), the same
+# kernels without the chain wave (+16384) and the opt-in pre-factorisation on matrix-core tiles (+32768, qpx_tsweep.h).
+@pytest.mark.parametrize("variant,rot", [(0, 0), (0, 1), (0, 2), (0, 3), (16384, 0), (32768, 0), (32768 + 16384, 0)])
+@pytest.mark.parametrize("shape", [(2, 30, 100, 0), (2, 20, 70, 3), (1, 100, 112, 0), (1, 10, 81, 0)])
+def test_chain_wave_form_and_tile_sweep(monkeypatch, variant, rot, shape):
+    B, n, m, q = shape
+    monkeypatch.setenv("QPX_EMU_SIMD_ROT", str(rot))
+    arrs = problems.prof_qp(B, n, m, q, seed=11)
+    dl = np.random.RandomState(5).randn(B, n)
+    xr, _, _, _, grads_ref, _ = orc.qp_forward_backward(*arrs, dl, per_qp=True, stall_policy=(1 if B == 1 else 2))
+    z, grads = run_qpf(arrs, dl, threads=256, variant=variant)
+    assert rel_err(z, xr).max() < TOL
+    for mine, ref in zip(grads, grads_ref):
+        if ref is not None and mine is not None:
+            assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", ["c1_b8_n10_m5_f64", "c3s_b4_n20_m10_q4_f64", "c2s_b4_n100_m100_f64", "edge_b2_n6_m4_q5"])
+def test_tile_sweep_against_the_reference(name):
+    """the opt-in pre-factorisation on matrix-core tiles (+32768) against the REFERENCE's outputs (golden vectors)"""
+    g = load_golden(name)
+    if "Q" in g:
+        arrs = [g[k] for k in ("Q", "p", "G", "h", "A", "b")]
+    else:                                  # the larger fixtures store (B, n, m, q, seed) of the generator instead of the inputs
+        arrs = list(problems.prof_qp(*[int(v) for v in g["shape"]]))
+    z, grads = run_qpf(arrs, g["dl_dz"], threads=256, variant=32768)
+    assert rel_err(z, g["zhat"]).max() < TOL
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g:
+            assert np.abs(gr - g[k]).max() <= 10 * TOL * max(1.0, np.abs(g[k]).max()), k
+
+
+def test_tile_sweep_reports_a_q_that_is_not_spd():
+    Q, p, G, h, A, b = [torch.tensor(x) for x in problems.prof_qp(2, 20, 70, 0, seed=3)]
+    Q = Q.clone()
+    Q[1] = -Q[1]
+    with emulated(256, 32768):
+        with pytest.raises(RuntimeError, match="Cannot perform LU factorization on Q"):     # batch.py:382-386
+            QPFunction(verbose=-1, check_Q_spd=False)(Q, p, G, h, A, b)
+
+
 @pytest.mark.parametrize("variant", LOOP_FORMS)
 @pytest.mark.parametrize("name", ["c1_b8_n10_m5_f64", "c3s_b4_n20_m10_q4_f64"])
 def test_every_loop_kernel_form_against_the_reference(variant, name):
