@@ -148,7 +148,12 @@ def table_prof_linear(dev, args):
                 if i:
                     fw.append(t1 - t0)
                     bw.append(t2 - t1)
-            rows.append({"table": "prof-linear", "dtype": dtype, "nBatch": B, "nz": nz, "nineq": nz, "neq": 0,
+            # what the kernels computed in: float32 tensors at the sizes the float64 tile kernels serve run in float64
+            # arithmetic (QPFunction(refine=None)); elsewhere the float32 kernels + two finishing iterations
+            from qpth_amd.qp import f64_arithmetic_serves
+            arith = "f64" if dtype == "f64" else ("f64 (QPX_F32_WIDE: float32 tensors, float64 factors and arithmetic)"
+                                                  if f64_arithmetic_serves(nz, nz, 0) else "f32 + 2 finishing iterations in f64 residuals")
+            rows.append({"table": "prof-linear", "dtype": dtype, "arithmetic": arith, "nBatch": B, "nz": nz, "nineq": nz, "neq": 0,
                          "forward_ms": float(np.median(fw)) * 1e3, "backward_ms": float(np.median(bw)) * 1e3,
                          "qps_fwd_bwd": B / (float(np.median(fw)) + float(np.median(bw))), "trials": ntr})
             print(json.dumps(rows[-1]), flush=True)
@@ -171,7 +176,7 @@ def table_prof_gurobi(dev, args):
             torch.cuda.synchronize()
             if i:
                 ts.append(time.perf_counter() - t0)
-        rows.append({"table": "prof-gurobi", "dtype": "f64", "nBatch": B, "nz": 100, "nineq": 100, "neq": 0,
+        rows.append({"table": "prof-gurobi", "dtype": "f64", "arithmetic": "f64", "nBatch": B, "nz": 100, "nineq": 100, "neq": 0,
                      "pre_factor_plus_forward_ms": float(np.median(ts)) * 1e3, "qps_forward": B / float(np.median(ts))})
         print(json.dumps(rows[-1]), flush=True)
     return rows

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define QPX_ABI_VERSION 4
+#define QPX_ABI_VERSION 5
 
 /* QPX_F32_WIDE (ABI v4): the caller's arrays are float32, `factors` and all arithmetic are float64 -- every `void*`
  * array below except `factors` has float elements, `factors` holds qpx_factor_elems(QPX_F32_WIDE, ...) DOUBLES.  On
@@ -89,6 +89,9 @@ int qpx_max_dim(void);
 /* QPX_OK if (dtype, n, m, q) is served under the calling thread's knob, else the QPX_ERR_* the entry points would
  * return (QPX_F32_WIDE: QPX_ERR_UNSUPPORTED outside the thread-grid / tile kernels' sizes) */
 int qpx_supported(int dtype, int n, int m, int q);
+/* v5: 1 if qpx_factor_solve_kkt / qpx_backward implement refine > 0 for this size and dtype (else they return
+ * QPX_ERR_UNSUPPORTED when asked to): the in-kernel iterative refinement of KKTSolvers.IR_UNOPT, batch.py:244-270. */
+int qpx_refine_supported(int dtype, int n, int m, int q);
 int qpx_fits_lds(int dtype, int n, int m, int q);
 
 /* tuning/A-B knob (per host thread): which kernel family runs.  0 (default) = automatic: the thread-grid /
@@ -153,7 +156,8 @@ int qpx_forward(int dtype, int B, int n, int m, int q,
  * refine > 0: that many steps of ITERATIVE REFINEMENT on the residual of the original KKT system
  * (qpth/solvers/pdipm/batch.py:228-270, kkt_resid_reg + solve_kkt_ir -- KKTSolvers.IR_UNOPT), evaluated with the
  * caller's Q (sQ), G (sG), A (sA) (batch strides in elements, 0 = shared); the factorisation is re-used, not repeated.
- * Implemented by the thread-grid / tile kernels (nz+neq+nineq <= 208); the other families ignore it. */
+ * Implemented by the thread-grid / tile kernels (nz+neq+nineq <= 208, dtype QPX_F32 / QPX_F64): qpx_refine_supported.
+ * Anywhere else refine > 0 returns QPX_ERR_UNSUPPORTED (v5; up to v4 the other kernel families ignored it). */
 int qpx_factor_solve_kkt(int dtype, int B, int n, int m, int q, void* factors, int64_t sfac,
                          const void* d, const void* rx, const void* rs, const void* rz, const void* ry,
                          void* dx, void* ds, void* dz, void* dy,

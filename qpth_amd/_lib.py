@@ -30,6 +30,7 @@ _SIGNATURES = {
     "qpx_factor_elems": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "qpx_max_dim": (_i, []),
     "qpx_supported": (_i, [_i, _i, _i, _i]),
+    "qpx_refine_supported": (_i, [_i, _i, _i, _i]),
     "qpx_fits_lds": (_i, [_i, _i, _i, _i]),
     "qpx_set_ipm_variant": (_i, [_i]),
     "qpx_get_ipm_variant": (_i, []),
@@ -112,7 +113,7 @@ class QpxLib:
                 continue
             fn = getattr(self.dll, name)       # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if strict and self.dll.qpx_abi_version() != 4:
+        if strict and self.dll.qpx_abi_version() != 5:
             raise RuntimeError("qpth_amd: ABI version mismatch in %s" % path)
 
     def check(self, code):

@@ -20,10 +20,17 @@
 
 namespace qpx {
 
-// Dynamic LDS above 64 KiB has to be opted into once per kernel symbol.
-template <class K> static int allow_big_lds(K kernel, size_t bytes, bool& done)
+// Dynamic LDS above 64 KiB has to be opted into once per kernel symbol AND DEVICE (the attribute belongs to the
+// device's copy of the code object): one flag per device of the process.
+constexpr int kMaxDevFlags = 16;
+struct BigLdsFlags { bool done[kMaxDevFlags] = {}; };
+template <class K> static int allow_big_lds(K kernel, size_t bytes, BigLdsFlags& flags)
 {
-    if (bytes <= 64 * 1024 || done) return QPX_OK;
+    if (bytes <= 64 * 1024) return QPX_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevFlags) return QPX_ERR_LAUNCH;
+    bool& done = flags.done[dev];
+    if (done) return QPX_OK;
     done = true;   // idempotent, so a benign race between host threads is harmless
     if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kMaxLdsBytes) != hipSuccess)
@@ -43,7 +50,7 @@ template <class T, int NS, bool kLds>
 int launch_prefactor(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_prefactor<T, NS, kLds>;
-    static bool big_lds_enabled = false;   // one flag per kernel instantiation
+    static BigLdsFlags big_lds_enabled;   // one set of flags per kernel instantiation
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -62,7 +69,7 @@ template <class T, int NS, bool kLds>
 int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_ipm<T, NS, kLds>;
-    static bool big_lds_enabled = false;   // one flag per kernel instantiation
+    static BigLdsFlags big_lds_enabled;   // one set of flags per kernel instantiation
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -81,7 +88,7 @@ template <class T, int NS, bool kLds, bool kBw>
 int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_kkt<T, NS, kLds, kBw>;
-    static bool big_lds_enabled = false;   // one flag per kernel instantiation
+    static BigLdsFlags big_lds_enabled;   // one set of flags per kernel instantiation
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -99,7 +106,7 @@ template <class T, int NBL> __global__ __launch_bounds__(256) void k_sweep(Prefa
 template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_sweep<T, NBL>;
-    static bool big_lds_enabled = false;
+    static BigLdsFlags big_lds_enabled;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -118,7 +125,7 @@ template <class T, int NBL, int NS> __global__ __launch_bounds__(256, (NBL <= 7 
 template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_ipm_grid<T, NBL, NS>;
-    static bool big_lds_enabled = false;
+    static BigLdsFlags big_lds_enabled;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -136,7 +143,7 @@ template <class T, int NBL, bool kBw> __global__ __launch_bounds__(256, (NBL <= 
 template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_kkt_grid<T, NBL, kBw>;
-    static bool big_lds_enabled = false;
+    static BigLdsFlags big_lds_enabled;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -155,7 +162,7 @@ template <class T, int NBL, int NS> __global__ __launch_bounds__(64) void k_ipm_
 template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_ipm_grid8<T, NBL, NS>;
-    static bool big_lds_enabled = false;
+    static BigLdsFlags big_lds_enabled;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(64), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -173,7 +180,7 @@ template <int NBL> __global__ __launch_bounds__(TSweep<NBL>::NT, 2) void k_tswee
 template <int NBL> int launch_tsweep(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_tsweep<NBL>;
-    static bool big_lds_enabled = false;
+    static BigLdsFlags big_lds_enabled;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(TSweep<NBL>::NT), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ipm_tile(IpmArgs<double> a)
 template <int NBL, int NW, int NS, bool CH> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_ipm_tile<NBL, NW, NS, CH>;
-    static bool big_lds_enabled = false;
+    static BigLdsFlags big_lds_enabled;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NW), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kkt_tile(KktArgs<double> a)
 template <int NBL, int NW, bool kBw, bool CH> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream)
 {
     auto kern = k_kkt_tile<NBL, NW, kBw, CH>;
-    static bool big_lds_enabled = false;
+    static BigLdsFlags big_lds_enabled;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NW), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
@@ -323,35 +330,35 @@ template <class T, int NS> __global__ __launch_bounds__(256) void k_big_diag(Big
     const Block b{(int)threadIdx.x, (int)blockDim.x};
     big_diag_body<T, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
 }
-template <class K, class A> static int big_launch(K kern, const A& a, int gx, int gy, int threads, size_t lds, void* stream, bool& big_ok)
+template <class K, class A> static int big_launch(K kern, const A& a, int gx, int gy, int threads, size_t lds, void* stream, BigLdsFlags& big_ok)
 {
     if (allow_big_lds(kern, lds, big_ok)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(threads), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
-template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void* s) { static bool f = false; return big_launch(k_big_pack<T>, a, a.B, gy, 256, 0, s, f); }
-template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void* s) { static bool f = false; return big_launch(k_big_panel<T>, a, a.B, 1, 256, big_panel_lds_elems() * sizeof(T), s, f); }
+template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void* s) { static BigLdsFlags f; return big_launch(k_big_pack<T>, a, a.B, gy, 256, 0, s, f); }
+template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_panel<T>, a, a.B, 1, 256, big_panel_lds_elems() * sizeof(T), s, f); }
 template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* s)
 {
-    static bool f = false;
+    static BigLdsFlags f;
     const size_t lds = big_gemm_lds_elems() * sizeof(T);
     const int ntiles = a.nti * a.ntj, swz = (a.B % 8 == 0 && ntiles > 1 && a.fuse && !a.no_swizzle) ? 1 : 0;   // measured (r02i): the trailing updates gain 3 %, R = Zt Zt^T (half its tiles empty) loses 30 %
     if (allow_big_lds(k_big_gemm<T>, lds, f)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(k_big_gemm<T>, swz ? dim3(a.B * ntiles) : dim3(a.B, ntiles), dim3(256), lds, (hipStream_t)s, a, ntiles, swz);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
-template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* s) { static bool f = false; return big_launch(k_big_trsv<T>, a, a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f); }
+template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_trsv<T>, a, a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f); }
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* s)
 {
-    static bool f = false;
+    static BigLdsFlags f;
     const int outs = a.trans ? a.cols : a.rows;
     return big_launch(k_big_gemv<T>, a, a.B, (outs + kBB - 1) / kBB, 256, 4 * kWave * sizeof(T), s, f);
 }
-template <class T> int launch_big_vec(const BigVecArgs<T>& a, void* s) { static bool f = false; return big_launch(k_big_vec<T>, a, a.B, 1, 256, 0, s, f); }
-template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* s) { static bool f = false; return big_launch(k_big_kkt<T>, a, a.B, gy, 256, 0, s, f); }
+template <class T> int launch_big_vec(const BigVecArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_vec<T>, a, a.B, 1, 256, 0, s, f); }
+template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* s) { static BigLdsFlags f; return big_launch(k_big_kkt<T>, a, a.B, gy, 256, 0, s, f); }
 template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* s)
 {
-    static bool f = false;
+    static BigLdsFlags f;
     const int ns = big_pad(a.m) / kWave;
     switch (ns) {
     case 1: return big_launch(k_big_phase<T, 1>, a, a.B, 1, 64, 0, s, f);
@@ -362,7 +369,7 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* s)
 }
 template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* s)
 {
-    static bool f = false;
+    static BigLdsFlags f;
     const size_t lds = big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T);
     const int ns = big_pad(a.ph.m) / kWave;
     switch (ns) {
@@ -374,7 +381,7 @@ template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* s)
 }
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* s)
 {
-    static bool f = false;
+    static BigLdsFlags f;
     const size_t lds = big_panel_lds_elems() * sizeof(T);
     const int ns = big_pad(a.ph.m) / kWave;
     switch (ns) {
@@ -393,20 +400,18 @@ QPX_INSTB(launch_big_vec, BigVecArgs) QPX_INSTB(launch_big_phase, BigPhaseArgs)
 #endif
 
 #if QPX_TU_KERNEL == 10
-template <class T> __global__ __launch_bounds__(64) void k_batch_outer(OuterArgs<T> a)
+template <class T> __global__ __launch_bounds__(64 * kOuterWaves) void k_batch_outer(OuterArgs<T> a)
 {
+    __shared__ T lds[kOuterWaves * 256];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    batch_outer_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y);
+    batch_outer_body<T>(b, a, (int)blockIdx.x, lds);
 }
-template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int chunks, void* stream)
+template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void* stream)
 {
-    if (a.use_atomics &&
-        hipMemsetAsync(a.out, 0, (size_t)a.r * a.c * sizeof(T), (hipStream_t)stream) != hipSuccess)
-        return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_batch_outer<T>, dim3(tiles, chunks), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_batch_outer<T>, dim3(tiles), dim3(64 * kOuterWaves), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
-template int launch_batch_outer<QPX_TU_REAL>(const OuterArgs<QPX_TU_REAL>&, int, int, void*);
+template int launch_batch_outer<QPX_TU_REAL>(const OuterArgs<QPX_TU_REAL>&, int, void*);
 #endif
 
 #if QPX_TU_KERNEL >= 1 && QPX_TU_KERNEL <= 3

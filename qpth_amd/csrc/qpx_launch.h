@@ -37,8 +37,8 @@ template <int NBL, int NW, bool kBw, bool CH = false> int launch_kkt_tile(const 
 template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void* stream);   // 8x8 grid = one wave
 template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void* stream);
 
-// batch-mean outer products of shared-parameter gradients (qpx_reduce.h): grid (tiles, batch chunks), one wave each
-template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int chunks, void* stream);
+// batch-mean outer products of shared-parameter gradients (qpx_reduce.h): one workgroup of 16 waves per output tile
+template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void* stream);
 
 // the large-QP family (qpx_big.h): every launch covers the batch; gy = workgroups per QP
 template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void* stream);

@@ -7,10 +7,11 @@
 //
 //     out = scale/B * ( U^T V + W^T X ),      U, W: (B, r)   V, X: (B, c),
 //
-// which is matrix-core work: one wave owns a 16x16 tile of `out` and walks the batch four QPs per
-// v_mfma_*_16x16x4 (operands are read straight from the (B, r) / (B, c) arrays: lane (g, c16) holds
-// batch item b0 + g, element 16 I + c16 -- 128 contiguous bytes per 16 lanes).  Long batches are split
-// over gridDim.y workgroups that add their partial tiles with atomics onto a zeroed `out`.
+// which is matrix-core work: a workgroup owns a 16x16 tile of `out`; its waves split the batch, each walking its part
+// four QPs per v_mfma_*_16x16x4 (operands are read straight from the (B, r) / (B, c) arrays: lane (g, c16) holds batch
+// item b0 + g, element 16 I + c16 -- 128 contiguous bytes per 16 lanes, sixteen QPs' operands in flight), and the
+// waves' partial tiles are added through LDS IN A FIXED ORDER: the result is bit-reproducible from run to run, as the
+// reference's `.mean(0)` is (round 2 split long batches over workgroups that added with atomics).
 #pragma once
 #include "qpx_kernels.h"
 
@@ -21,38 +22,46 @@ template <class T> struct OuterArgs {
     const T *u, *v, *w, *x;
     T scale;          // already divided by B
     T* out;
-    int bchunk;       // batch items per workgroup (multiple of 4)
-    int use_atomics;  // gridDim.y > 1
 };
+constexpr int kOuterWaves = 16;      // waves per workgroup = parts of the batch
 
-template <class T> QPX_DEV void batch_outer_body(const Block& b, const OuterArgs<T>& a, int tile, int chunk)
+// lds: kOuterWaves x 256 partial tiles
+template <class T> QPX_DEV void batch_outer_body(const Block& b, const OuterArgs<T>& a, int tile, T* lds)
 {
     const int tc = (a.c + 15) >> 4;
     const int I = tile / tc, J = tile - I * tc;
-    const int lane = b.lane(), g = lane >> 4, c16 = lane & 15;
+    const int lane = b.lane(), g = lane >> 4, c16 = lane & 15, wv = b.uniform(b.wave()), nw = b.nwaves();
     const int ri = 16 * I + c16, cj = 16 * J + c16;
     const bool rok = ri < a.r, cok = cj < a.c;
-    const int b0 = chunk * a.bchunk;
-    const int b1 = (b0 + a.bchunk < a.B) ? b0 + a.bchunk : a.B;
+    // this wave's part of the batch: multiples of 16 QPs, dealt round-robin (16 QPs = four MFMA pairs per trip)
     T acc[4] = {T(0), T(0), T(0), T(0)};
-    for (int bb = b0; bb < b1; bb += 4) {
-        const int bi = bb + g;
-        const bool bok = bi < b1;
-        const T au = (bok && rok) ? a.u[(size_t)bi * a.r + ri] : T(0);
-        const T bv = (bok && cok) ? a.v[(size_t)bi * a.c + cj] : T(0);
-        const T aw = (bok && rok) ? a.w[(size_t)bi * a.r + ri] : T(0);
-        const T bx = (bok && cok) ? a.x[(size_t)bi * a.c + cj] : T(0);
-        b.mfma16x16x4(au, bv, acc);
-        b.mfma16x16x4(aw, bx, acc);
+    for (int bb = 16 * wv; bb < a.B; bb += 16 * nw) {
+        T au[4], bv[4], aw[4], bx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int bi = bb + 4 * k + g;
+            const bool bok = bi < a.B;
+            au[k] = (bok && rok) ? a.u[(size_t)bi * a.r + ri] : T(0);
+            bv[k] = (bok && cok) ? a.v[(size_t)bi * a.c + cj] : T(0);
+            aw[k] = (bok && rok) ? a.w[(size_t)bi * a.r + ri] : T(0);
+            bx[k] = (bok && cok) ? a.x[(size_t)bi * a.c + cj] : T(0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b.mfma16x16x4(au[k], bv[k], acc);
+            b.mfma16x16x4(aw[k], bx[k], acc);
+        }
     }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int i = 16 * I + Block::mfma_row(T(0), g, rr), j = cj;
-        if (i < a.r && j < a.c) {
-            T* o = a.out + (size_t)i * a.c + j;
-            const T val = a.scale * acc[rr];
-            if (a.use_atomics) atomic_add_(o, val);
-            else *o = val;
+    for (int rr = 0; rr < 4; ++rr) lds[(wv * 4 + rr) * 64 + lane] = acc[rr];
+    b.sync();
+    if (wv == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            T sum = T(0);
+            for (int k = 0; k < nw; ++k) sum += lds[(k * 4 + rr) * 64 + lane];
+            const int i = 16 * I + Block::mfma_row(T(0), g, rr), j = cj;
+            if (i < a.r && j < a.c) a.out[(size_t)i * a.c + j] = a.scale * sum;
         }
     }
 }

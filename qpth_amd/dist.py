@@ -18,6 +18,21 @@ def shard_bounds(nBatch, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def check_shardable(params, nBatch, world, ndims=(3, 2, 3, 2, 3, 2)):
+    """Refuse, identically on EVERY rank (the decision depends on nBatch, world and the tensors' ranks only, never on the
+    rank's own slice), what cannot be sharded -- before any rank enters a collective the others would then hang in:
+    a batch smaller than the world (some rank's slice would be empty) and a batch size that no parameter carries
+    (all of Q, p, G, h, A, b un-batched: every rank would solve the same single QP)."""
+    if nBatch < world:
+        raise RuntimeError("qpth_amd.dist: a batch of %d cannot be sharded over %d ranks (empty slices)" % (nBatch, world))
+    batched = [X for X, nd in zip(params, ndims) if X.nelement() > 0 and X.dim() == nd]
+    if not batched:
+        raise RuntimeError("qpth_amd.dist: no parameter is batched; there is nothing to shard (nBatch = %d)" % nBatch)
+    for X in batched:
+        if X.size(0) != nBatch:
+            raise RuntimeError("qpth_amd.dist: a batched parameter has %d rows, nBatch is %d" % (X.size(0), nBatch))
+
+
 def shard_params(params, nBatch, rank, world, ndims=(3, 2, 3, 2, 3, 2)):
     """slice batched parameters, pass un-batched / empty ones through (qpth/util.py:44-50)"""
     lo, hi = shard_bounds(nBatch, rank, world)
@@ -56,6 +71,7 @@ def solve_sharded(qp_function, Q, p, G, h, A, b, nBatch, gather=True, group=None
     """Solve the global batch data-parallel: this rank's slice through `qp_function`
     (a QPFunction(...) callable); returns the local zhat and, if gather, the full one."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    check_shardable([Q, p, G, h, A, b], nBatch, world)
     lQ, lp, lG, lh, lA, lb = shard_params([Q, p, G, h, A, b], nBatch, rank, world)
     z_local = qp_function(lQ, lp, lG, lh, lA, lb)
     if not gather:
@@ -71,6 +87,7 @@ def forward_sharded(Q, p, G, h, A, b, nBatch, gather=True, group=None, **kw):
     from .solvers.pdipm import batch as pdipm_b
     from .util import expandParam, extract_nBatch
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    check_shardable([Q, p, G, h, A, b], nBatch, world)
     local_params = shard_params([Q, p, G, h, A, b], nBatch, rank, world)
     nloc = extract_nBatch(*local_params)
     # un-batched parameters become stride-0 views over the slice, as in QPFunction (qpth/qp.py:63-70): the solver

@@ -96,14 +96,17 @@ class KKTFactors:
         # factors are built under and re-apply it around every later call on them (autograd runs backward
         # on its own thread)
         self.variant = int(self.lib.dll.qpx_get_ipm_variant())
+        # does the kernel family that serves this size refine KKT solves in the kernel (qpx_factor_solve_kkt(..., refine))?
+        self.refine_ok = bool(self.lib.dll.qpx_refine_supported(code, self.n, self.m, self.q))
         share_ok = bool(self.lib.dll.qpx_can_share_factors(code, self.n, self.m, self.q))
         self.shared = B > 1 and share_ok and _is_shared(Q, B) and _is_shared(G, B) and _is_shared(A, B)
         nblob = 1 if self.shared else B
         self.sfac = 0 if self.shared else self.elems
         self.blob = torch.empty(nblob * self.elems, dtype=torch.float64 if self.wide else Q.dtype, device=Q.device)
         self.status = torch.empty(B, dtype=torch.int32, device=Q.device)      # every pre-factorisation kernel writes it
-        self.lib.pre_factor(nblob, self.n, self.m, self.q, Q, G, A if self.q else None, self.blob, self.status,
-                            wide=self.wide)
+        with self._knob():
+            self.lib.pre_factor(nblob, self.n, self.m, self.q, Q, G, A if self.q else None, self.blob, self.status,
+                                wide=self.wide)
         if self.shared:
             self.status[1:] = self.status[0]
         # The reference raises on a bad Q / A from inside forward (qp.py:81-85, batch.py:379-386).  The two
@@ -121,10 +124,15 @@ class KKTFactors:
 
     @contextlib.contextmanager
     def _knob(self):
+        """around every launch on these factors: the library's A/B knob as it was when they were built, and THEIR
+        device current (the launchers opt kernels into > 64 KiB of LDS per device and fork side streams from the
+        current device's pool: tensors on cuda:1 while cuda:0 is current must not reach them that way)"""
         dll = self.lib.dll
         old = dll.qpx_set_ipm_variant(self.variant)
+        guard = torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
         try:
-            yield
+            with guard:
+                yield
         finally:
             dll.qpx_set_ipm_variant(old)
 
@@ -218,16 +226,26 @@ a non-zero diagonal.
     def polish(self, p, h, b, res, steps=2, refine=1):
         """`steps` iterations of the reference's PDIPM loop (batch.py:92-198: affine + centring-corrector) in the ORIGINAL
         variables (x, s, z, y), started from the loop kernel's result, with the KKT residuals evaluated from the
-        caller's Q, G, A in float64 and every solve refined in the kernel (solve_kkt(..., refine)).  The loop kernel iterates on pre-computed products (R = G Q^-1 G^T, ...): in float32
-        their rounding error (cond(Q) ~ 1e6 on the benchmark generator) is a perturbation of the PROBLEM that no
-        number of loop iterations removes; residuals against the original data do.  No host sync."""
+        caller's Q, G, A in float64 and every solve refined in the kernel (solve_kkt(..., refine)) where the kernel family
+        implements that (refine_ok; elsewhere the plain solve).  The loop kernel iterates on pre-computed products
+        (R = G Q^-1 G^T, ...): in float32 their rounding error (cond(Q) ~ 1e6 on the benchmark generator) is a
+        perturbation of the PROBLEM that no number of loop iterations removes; residuals against the original data do.
+        As in the reference's loop (batch.py:118-139) the BEST iterate is kept per QP -- by the reference's residual
+        ||rx|| + ||rz|| + ||ry|| + nineq mu, strict <, NaN never wins -- so a step that does not help (a QP the loop left
+        at maxIter, an oscillating mu) cannot make the answer worse.  No host sync."""
         B, n, m, q = self.B, self.n, self.m, self.q
         hp = torch.float64
-        ex = lambda X, nd: (X if X.dim() == nd else X.unsqueeze(0).expand(B, *X.shape)).to(hp)   # noqa: E731
-        Q, G = ex(self.Q, 3), ex(self.G, 3)
-        pp, hh = ex(p, 2), ex(h, 2)
-        A = ex(self.A, 3) if q else None
-        bb = ex(b, 2) if q else None
+        if not self.refine_ok:
+            refine = 0
+        # shared parameters stay un-batched: `.to(float64)` on a stride-0 expanded view would densify it (0.5 GB at C4)
+        w = lambda X: (X[0] if (X.dim() == 3 and X.size(0) == B and X.stride(0) == 0 and B > 1) else X).to(hp)   # noqa: E731
+        Q, G = w(self.Q), w(self.G)
+        A = w(self.A) if q else None
+        mv = lambda M, x: torch.einsum("ij,bj->bi", M, x) if M.dim() == 2 else torch.einsum("bij,bj->bi", M, x)      # noqa: E731
+        mtv = lambda M, x: torch.einsum("ij,bi->bj", M, x) if M.dim() == 2 else torch.einsum("bij,bi->bj", M, x)     # noqa: E731
+        ex = lambda X: (X if X.dim() == 2 else X.unsqueeze(0).expand(B, *X.shape)).to(hp)   # noqa: E731
+        pp, hh = ex(p), ex(h)
+        bb = ex(b) if q else None
         x, z, s = res.zhat.to(hp), res.lam.to(hp), res.slacks.to(hp)
         y = res.nu.to(hp) if q else None
         tiny = torch.finfo(self.dtype).tiny
@@ -241,17 +259,26 @@ a non-zero diagonal.
             o = self.solve_kkt(d.to(dt), rx.to(dt), rs.to(dt), rz.to(dt), ry.to(dt) if q else None, refine=refine)
             return [v.to(hp) if v is not None else None for v in o]
 
-        for _ in range(steps):
-            # one iteration of the reference's loop (batch.py:92-198) in float64 vector arithmetic
-            rx = torch.einsum("bij,bj->bi", Q, x) + pp + torch.einsum("bmi,bm->bi", G, z)
-            rz = torch.einsum("bmi,bi->bm", G, x) + s - hh
+        def residuals(x, s, z, y):
+            rx = mv(Q, x) + pp + mtv(G, z)
+            rz = mv(G, x) + s - hh
             ry = None
             if q:
-                rx = rx + torch.einsum("bqi,bq->bi", A, y)
-                ry = torch.einsum("bqi,bi->bq", A, x) - bb
+                rx = rx + mtv(A, y)
+                ry = mv(A, x) - bb
+            mu = (s * z).sum(1, keepdim=True).abs() / m
+            tot = rx.norm(dim=1, keepdim=True) + rz.norm(dim=1, keepdim=True) + m * mu     # batch.py:103-107
+            if q:
+                tot = tot + ry.norm(dim=1, keepdim=True)
+            return rx, rz, ry, mu, tot
+
+        rx, rz, ry, mu, best_r = residuals(x, s, z, y)
+        best_r = torch.where(torch.isfinite(best_r), best_r, torch.full_like(best_r, float("inf")))
+        bx, bs, bz, by = x, s, z, y
+        for _ in range(steps):
+            # one iteration of the reference's loop (batch.py:92-198) in float64 vector arithmetic
             sc, zc = s.clamp_min(tiny), z.clamp_min(tiny)
             d = zc / sc
-            mu = (s * z).sum(1, keepdim=True).abs() / m
             dxa, dsa, dza, dya = solve(d, rx, z, rz, ry)                                        # affine direction
             al = torch.minimum(step(z, dza), step(s, dsa)).clamp_max(1.0)
             sig = (((s + al * dsa) * (z + al * dza)).sum(1, keepdim=True) / (s * z).sum(1, keepdim=True)) ** 3
@@ -263,9 +290,15 @@ a non-zero diagonal.
             x, s, z = x + alpha * dx, s + alpha * ds, z + alpha * dz
             if q:
                 y = y + alpha * (dya + dyc)
-        res.zhat, res.lam, res.slacks = x.to(self.dtype), z.to(self.dtype), s.to(self.dtype)
+            rx, rz, ry, mu, tot = residuals(x, s, z, y)
+            better = tot < best_r                                   # False for NaN: a non-finite iterate never wins
+            best_r = torch.where(better, tot, best_r)
+            bx, bs, bz = torch.where(better, x, bx), torch.where(better, s, bs), torch.where(better, z, bz)
+            if q:
+                by = torch.where(better, y, by)
+        res.zhat, res.lam, res.slacks = bx.to(self.dtype), bz.to(self.dtype), bs.to(self.dtype)
         if q:
-            res.nu = y.to(self.dtype)
+            res.nu = by.to(self.dtype)
         return res
 
     # -- QPFunctionFn.backward (qp.py:127-182) ------------------------------------------------
@@ -287,14 +320,19 @@ a non-zero diagonal.
         dQ = buf(wQ and not sQ, B, n, n)
         dG = buf(wG and not sG, B, m, n)
         dA = buf(wA and not sA, B, q, n)
-        need_dx = wp or (wQ and sQ) or (wG and sG) or (wA and sA)
-        dx = buf(need_dx, B, n)                                   # dp = dx  (qp.py:157)
-        dz = buf(wh or (wG and sG), B, m)                         # dh = -dz (qp.py:161)
-        dy = buf(q > 0 and (wb or (wA and sA)), B, q)             # db = -dy (qp.py:166)
+        # per-QP vector gradients come out of the kernel as they are (dp = dx, dh = -dz, db = -dy: qp.py:157-166; the
+        # kernel writes the signs, no elementwise launches behind it); the KKT solution itself (dx, dz, dy) is only asked
+        # for when a batch-shared parameter needs it: one contraction / mean over the batch
+        dp = buf(wp and not sp, B, n)
+        dh = buf(wh and not sh, B, m)
+        db = buf(wb and not sb, B, q)
+        dx = buf((wp and sp) or (wQ and sQ) or (wG and sG) or (wA and sA), B, n)
+        dz = buf((wh and sh) or (wG and sG), B, m)
+        dy = buf(q > 0 and ((wb and sb) or (wA and sA)), B, q)
         zh, lm, nv = self._vec(zhat, n, "zhat"), self._vec(lam, m, "lam"), self._vec(nu, q, "nu")
         with self._knob():
             self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m, "slacks"), nv,
-                              self._vec(dl_dz, n, "dl_dz"), dQ, None, dG, None, dA, None, self.status, dx, dz, dy,
+                              self._vec(dl_dz, n, "dl_dz"), dQ, dp, dG, dh, dA, db, self.status, dx, dz, dy,
                               refine=refine, Q=self.Q, G=self.G, A=self.A, wide=self.wide)
         if wQ and sQ:
             dQ = torch.empty(n, n, dtype=dt, device=dev)
@@ -305,7 +343,10 @@ a non-zero diagonal.
         if wA and sA:
             dA = torch.empty(q, n, dtype=dt, device=dev)
             self.lib.batch_outer(dy, zh, nv, dx, 1.0, dA)
-        dp = (dx.mean(0) if sp else dx) if wp else None
-        dh = ((-dz).mean(0) if sh else -dz) if wh else None
-        db = ((-dy).mean(0) if sb else -dy) if wb else None
+        if wp and sp:
+            dp = dx.mean(0)
+        if wh and sh:
+            dh = -dz.mean(0)
+        if wb and sb:
+            db = -dy.mean(0)
         return dQ, dp, dG, dh, dA, db

@@ -129,7 +129,8 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
             # the batch instead of nBatch outer products.
             want = tuple(ctx.needs_input_grad[:6])
             grads = fac.backward(zhats, ctx.lams, ctx.slacks, ctx.nus, dl_dzhat, want=want,
-                                 shared=(Q_e, p_e, G_e, h_e, A_e, b_e), refine=1 if ctx.refine > 0 else 0)
+                                 shared=(Q_e, p_e, G_e, h_e, A_e, b_e),
+                                 refine=1 if (ctx.refine > 0 and fac.refine_ok) else 0)
             if neq == 0:
                 grads = grads[:4] + (None, None)
             return grads

@@ -83,11 +83,61 @@ def solve_kkt(Q_LU, d, G, A, S_LU, rx, rs, rz, ry):
     return fac.solve_kkt(d, rx, rs, rz, ry)
 
 
-def solve_kkt_ir(Q_LU, d, G, A, S_LU, rx, rs, rz, ry, niter=1):
-    """The reference's solve_kkt_ir (batch.py:244-270) on the pre-factored handles: solve, then `niter` steps of
-    iterative refinement on the residual of the original KKT system (kkt_resid_reg, batch.py:228-241) -- inside the
-    kernel, with the factorisation re-used.  (No eps-regularisation: the un-pivoted factorisations here need none.)"""
-    return Q_LU.fac.solve_kkt(d, rx, rs, rz, ry, refine=niter)
+def _diag_of(D):
+    """the reference passes D = diag(d) as a (nBatch, nineq, nineq) matrix to its full-system solvers"""
+    return torch.diagonal(D, dim1=-2, dim2=-1).contiguous() if D.dim() >= 2 and D.size(-1) == D.size(-2) and D.dim() == 3 else D
+
+
+def solve_kkt_ir(*args, niter=1):
+    """solve_kkt_ir (batch.py:244-270): solve, then `niter` steps of iterative refinement on the residual of the
+    original KKT system (kkt_resid_reg, batch.py:228-241) -- inside the kernel, with the factorisation re-used.
+    Two call forms:
+      solve_kkt_ir(Q, D, G, A, rx, rs, rz, ry, niter=1)             the reference's (D = diag(d) as a matrix): factors first
+      solve_kkt_ir(Q_LU, d, G, A, S_LU, rx, rs, rz, ry, niter=1)    on handles from pre_factor_kkt
+    (No eps-regularisation: the un-pivoted symmetric factorisations here need none, and the correction is added with
+    the right sign -- DESIGN.md, deliberate differences 7.)  Raises where the kernel family that serves the size has no
+    in-kernel refinement (nz + neq + nineq > 208: qpx_refine_supported)."""
+    if isinstance(args[0], _Handle):
+        Q_LU, d, G, A, S_LU, rx, rs, rz, ry = args[:9]
+        if len(args) > 9:
+            niter = args[9]
+        return Q_LU.fac.solve_kkt(d, rx, rs, rz, ry, refine=niter)
+    Q, D, G, A, rx, rs, rz, ry = args[:8]
+    if len(args) > 8:
+        niter = args[8]
+    fac = _dp.KKTFactors.build(Q, G, A)
+    fac.raise_on_failure()
+    return fac.solve_kkt(_diag_of(D), rx, rs, rz, ry, refine=niter)
+
+
+def factor_solve_kkt(Q, D, G, A, rx, rs, rz, ry):
+    """factor_solve_kkt (batch.py:313-346, KKTSolvers.LU_FULL): the whole KKT system factored and solved in one call,
+    D = diag(d) as a (nBatch, nineq, nineq) matrix.  The reference eliminates (x, s) first, this library z first --
+    two orders of one system (test.py:222-234 checks they agree); here: pre_factor_kkt + the fused factor / solve."""
+    fac = _dp.KKTFactors.build(Q, G, A)
+    fac.raise_on_failure()
+    return fac.solve_kkt(_diag_of(D), rx, rs, rz, ry)
+
+
+def factor_solve_kkt_reg(Q_tilde, D, G, A, rx, rs, rz, ry, eps):
+    """factor_solve_kkt_reg (batch.py:273-310): the KKT system with -eps I in the (z, z) and (y, y) blocks,
+        Q~ dx + G^T dz + A^T dy = -rx,  D ds + dz = -rs,  G dx + ds - eps dz = -rz,  A dx - eps dy = -ry.
+    Without equality constraints the regularisation is a change of the diagonal -- eliminating ds leaves
+    G dx - (1/d + eps) dz = -rz + rs/d, i.e. the un-regularised system with d' = d / (1 + eps d) and rs' = rs d'/d -- and
+    runs on the same kernels.  With equality constraints it would need A Q~^-1 A^T + eps I inside the pre-factorisation, which
+    the kernels do not offer: NotImplementedError (use solve_kkt_ir, whose refinement needs no regularisation)."""
+    nineq, nz, neq, nBatch = get_sizes(G, A)
+    if neq > 0:
+        raise NotImplementedError("qpth_amd: factor_solve_kkt_reg with equality constraints (the -eps I block of dy) is "
+                                  "not built; solve_kkt_ir refines without regularisation")
+    d = _diag_of(D)
+    fac = _dp.KKTFactors.build(Q_tilde, G, A)
+    fac.raise_on_failure()
+    dreg = d / (1.0 + eps * d)
+    rs_ = rs if rs is not None else torch.zeros_like(rz if rz is not None else d.expand(nBatch, nineq))
+    dx, _, dz, dy = fac.solve_kkt(dreg, rx, rs_ / (1.0 + eps * d), rz, ry)
+    ds = (-rs_ - dz) / (d if d.dim() == 2 else d.unsqueeze(0))      # the second block row with the caller's d
+    return dx, ds, dz, dy
 
 
 def forward(Q, p, G, h, A, b, Q_LU, S_LU, R, eps=1e-12, verbose=0, notImprovedLim=3,

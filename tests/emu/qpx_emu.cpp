@@ -427,12 +427,12 @@ template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void*)
     return QPX_OK;
 }
 
-template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, int chunks, void*)
+template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void*)
 {
-    if (a.use_atomics)
-        for (size_t e = 0; e < (size_t)a.r * a.c; ++e) a.out[e] = T(0);
-    for (int ch = 0; ch < chunks; ++ch)
-        for (int t = 0; t < tiles; ++t) run_block(64, [&](const Block& b) { batch_outer_body<T>(b, a, t, ch); });
+    for (int t = 0; t < tiles; ++t) {
+        std::vector<T> lds((size_t)kOuterWaves * 256);
+        run_block(64 * kOuterWaves, [&](const Block& b) { batch_outer_body<T>(b, a, t, lds.data()); });
+    }
     return QPX_OK;
 }
 

@@ -62,7 +62,8 @@ int main(int argc, char** argv)
     std::vector<double> dA((size_t)B * q * n + 1), db((size_t)B * q + 1), dx((size_t)B * n), dz((size_t)B * m), dy((size_t)B * q + 1);
     rc = qpx_backward(QPX_F64, B, n, m, q, fac.data(), (int64_t)fe, zhat.data(), lam.data(), sl.data(), q ? nu.data() : nullptr, g.data(),
                       dQ.data(), dp.data(), dG.data(), dh.data(), q ? dA.data() : nullptr, q ? db.data() : nullptr,
-                      dx.data(), dz.data(), q ? dy.data() : nullptr, 1, Q.data(), (int64_t)n * n, G.data(), (int64_t)m * n,
+                      dx.data(), dz.data(), q ? dy.data() : nullptr, qpx_refine_supported(QPX_F64, n, m, q) ? 1 : 0 /* one refinement step where the family has it (ABI v5: refused elsewhere) */,
+                      Q.data(), (int64_t)n * n, G.data(), (int64_t)m * n,
                       q ? A.data() : nullptr, (int64_t)q * n, status.data(), nullptr);
     if (rc) { fprintf(stderr, "backward rc %d\n", rc); return 2; }
     // the shared-parameter reduction (batch-mean of dQ as one contraction over the batch)

@@ -484,6 +484,101 @@ def test_forward_accepts_every_kkt_solver(solver):
     assert rel_err(y.numpy(), g["nu"]).max() < TOL
 
 
+def _kkt_solver_golden():
+    g = load_golden("kkt_solver")
+    Qg, Gg, Ag = tens([g[k] for k in ("Q", "G", "A")], grad=False)
+    Qe, Ae = Qg.unsqueeze(0).expand(2, 5, 5), Ag.unsqueeze(0).expand(2, 3, 5)
+    d, rx, rs, rz, ry = tens([g[k] for k in ("d", "rx", "rs", "rz", "ry")], grad=False)
+    return g, Qe, Gg, Ae, d, rx, rs, rz, ry
+
+
+def test_full_system_solvers_with_the_reference_signatures():
+    """factor_solve_kkt(Q, D, G, A, rx, rs, rz, ry) and solve_kkt_ir(Q, D, G, A, ..., niter) (batch.py:244-270, 313-346; D =
+    diag(d) as a matrix) against the reference's own factor_solve_kkt outputs (test.py:222-247, golden full_*)."""
+    g, Qe, Gg, Ae, d, rx, rs, rz, ry = _kkt_solver_golden()
+    D = torch.diag_embed(d)
+    with emulated():
+        full = pdipm_b.factor_solve_kkt(Qe, D, Gg, Ae, rx, rs, rz, ry)
+        ir = pdipm_b.solve_kkt_ir(Qe, D, Gg, Ae, rx, rs, rz, ry, niter=1)
+    for a, c, key in zip(full, ir, ("dx", "ds", "dz", "dy")):
+        assert np.allclose(a.numpy(), g["full_" + key], rtol=1e-8, atol=1e-9), key
+        assert np.allclose(c.numpy(), g["full_" + key], rtol=1e-8, atol=1e-9), key
+
+
+def _dense_reg_solve(Q, D, G, rx, rs, rz, eps):
+    """the regularised KKT system of batch.py:273-310 (neq = 0) solved densely in numpy"""
+    n, m = Q.shape[0], G.shape[0]
+    K = np.zeros((n + 2 * m, n + 2 * m))
+    K[:n, :n] = Q; K[:n, n + m:] = G.T
+    K[n:n + m, n:n + m] = D; K[n:n + m, n + m:] = np.eye(m)
+    K[n + m:, :n] = G; K[n + m:, n:n + m] = np.eye(m); K[n + m:, n + m:] = -eps * np.eye(m)
+    sol = np.linalg.solve(K, -np.concatenate([rx, rs, rz]))
+    return sol[:n], sol[n:n + m], sol[n + m:]
+
+
+def test_regularised_full_solve():
+    """factor_solve_kkt_reg (batch.py:273-310): without equality constraints the -eps I block is a change of d; with
+    them it is refused by name."""
+    B, n, m = 3, 12, 9
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, 0, seed=4)
+    r = np.random.RandomState(2)
+    d = r.rand(B, m) + 0.1
+    rx, rs, rz = r.randn(B, n), r.randn(B, m), r.randn(B, m)
+    eps = 1e-3
+    e = torch.empty(0, dtype=torch.float64)
+    with emulated():
+        dx, ds, dz, dy = pdipm_b.factor_solve_kkt_reg(torch.tensor(Q), torch.diag_embed(torch.tensor(d)), torch.tensor(G), e,
+                                                      torch.tensor(rx), torch.tensor(rs), torch.tensor(rz), None, eps)
+    assert dy is None
+    for i in range(B):
+        ex, es, ez = _dense_reg_solve(Q[i], np.diag(d[i]), G[i], rx[i], rs[i], rz[i], eps)
+        for mine, ref in ((dx[i], ex), (ds[i], es), (dz[i], ez)):
+            assert np.abs(mine.numpy() - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+    g, Qe, Gg, Ae, dd, rxx, rss, rzz, ryy = _kkt_solver_golden()
+    with pytest.raises(NotImplementedError, match="equality"):
+        pdipm_b.factor_solve_kkt_reg(Qe, torch.diag_embed(dd), Gg, Ae, rxx, rss, rzz, ryy, 1e-7)
+
+
+def test_refinement_is_refused_loudly_where_no_kernel_implements_it():
+    """qpx_factor_solve_kkt(refine > 0) on a kernel family without in-kernel refinement: QPX_ERR_UNSUPPORTED (ABI v5),
+    never a silently un-refined answer; the finishing stage then runs with plain solves."""
+    Q, p, G, h, A, b = [torch.tensor(x) for x in problems.prof_qp(1, 20, 70, 0, seed=1)]
+    r = np.random.RandomState(0)
+    d, rx, rs, rz = [torch.tensor(v) for v in (r.rand(1, 70) + 0.1, r.randn(1, 20), r.randn(1, 70), r.randn(1, 70))]
+    with emulated(256, 3):                       # knob 3: the large-QP family
+        Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(Q, G, A)
+        assert not Q_LU.fac.refine_ok
+        pdipm_b.solve_kkt(Q_LU, d, G, A, S_LU, rx, rs, rz, None)
+        with pytest.raises(RuntimeError, match="not supported"):
+            pdipm_b.solve_kkt_ir(Q_LU, d, G, A, S_LU, rx, rs, rz, None, niter=1)
+    with emulated(256, 0):
+        assert pdipm_b.pre_factor_kkt(Q, G, A)[0].fac.refine_ok
+
+
+def test_finishing_steps_keep_the_best_iterate():
+    """KKTFactors.polish keeps, per QP, the iterate with the smallest residual (batch.py:118-139): finishing steps on a
+    QP the float32 loop could not finish must not make the answer worse (advisor finding of round 2: 1.4e-6 -> 3.6e-3
+    without the guard)."""
+    rng = np.random.RandomState(7)
+    B, n, m = 3, 20, 18
+    L = rng.rand(n, n)
+    Q = (L @ L.T + 1e-3 * np.eye(n)).astype(np.float32)
+    G = rng.randn(m, n).astype(np.float32)
+    z0, s0 = rng.randn(B, n), rng.rand(B, m)
+    p = rng.randn(B, n).astype(np.float32)
+    h = (z0 @ G.T.astype(np.float64) + s0).astype(np.float32)
+    e = np.zeros(0, np.float32)
+    ref, _ = run_qpf([Q.astype(np.float64), p.astype(np.float64), G.astype(np.float64), h.astype(np.float64), e, e],
+                     np.zeros((B, n)), variant=256)
+    errs = {}
+    for refine in (0, 2, 5):
+        tq = tens([Q, p, G, h, e, e], torch.float32, grad=False)
+        with emulated(128, 256):
+            z = QPFunction(verbose=-1, refine=refine)(*tq)
+        errs[refine] = rel_err(z.numpy(), ref).max()
+    assert errs[2] <= 2 * errs[0] + 1e-6 and errs[5] <= 2 * errs[0] + 1e-6, errs
+
+
 def test_float32_finishing_steps_reach_the_reference_accuracy():
     """QPFunction in float32: the loop kernel alone (refine=0) lands ~1e-4 from the float64 answer on the benchmark
     generator (cond(Q) ~ 1e6); with finishing steps (refine=2) it is as close as the reference's own float32 run, and
@@ -555,7 +650,7 @@ def test_f32_wide_abi_surface():
         fac = KKTFactors.build(tq[0], tq[2], tq[4], wide=True)
         assert fac.blob.dtype == torch.float64
         d = torch.ones(4, 10)
-        with pytest.raises(RuntimeError, match="code -1"):
+        with pytest.raises(RuntimeError, match="code -2"):     # QPX_ERR_UNSUPPORTED since ABI v5
             fac.solve_kkt(d, tq[1], d, d, tq[5], refine=1)
         # the general KKT solve through the wide interface = the float64 solve of the same data, to float32 rounding
         outs32 = fac.solve_kkt(d, tq[1], d, d, tq[5])

@@ -81,3 +81,26 @@ def test_rccl_batch_sharding(tmp_path):
     x1, nu1, lam1, s1 = pdipm_b.forward(Qe, tp.detach(), tG, th, tA, tb, Q_LU, S_LU, R, verbose=-1)
     assert rel_err(out["x"], x1.cpu().numpy()).max() < 1e-9 and rel_err(out["nu"], nu1.cpu().numpy()).max() < 1e-9
     assert rel_err(out["lam"], lam1.cpu().numpy()).max() < 1e-9 and np.abs(out["s"] - s1.cpu().numpy()).max() < 1e-9
+
+
+def test_bench_strong_scaling_contract_under_torchrun(tmp_path):
+    """bench.py --config c5 --gpus N under torch.distributed.run, as the driver launches it: one JSON line from rank 0
+    with the strong-scaling contract (fixed global batch of 65 536 sharded over the N ranks, the gather inside the
+    timed region).  Needs >= 2 visible GPUs."""
+    import json
+    import subprocess
+    import sys
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("RCCL PATH NOT EXERCISED: %d GPU visible on this box (needs >= 2)" % world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--config", "c5", "--gpus", str(world),
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, check=True, env=env).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["global_batch"] == 65536
+    assert d["value"] > 0 and d["steps"] == 3

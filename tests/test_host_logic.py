@@ -60,3 +60,16 @@ def test_inconsistent_sizes_are_an_error_before_any_launch():
 
 def test_default_stall_policy_is_the_reference_counter_for_one_qp():
     assert default_stall_policy(1) == _lib.STALL_REFERENCE and default_stall_policy(2) == _lib.STALL_FLOOR
+
+
+def test_sharded_solves_refuse_what_cannot_be_sharded():
+    """the same error on every rank, before any collective: a batch smaller than the world, nothing batched"""
+    import torch
+    from qpth_amd import dist as qdist
+    Q, p = torch.eye(3), torch.zeros(2, 3)
+    e = torch.empty(0)
+    with pytest.raises(RuntimeError, match="cannot be sharded"):
+        qdist.check_shardable([Q, p, torch.ones(1, 3), torch.ones(1), e, e], 2, 4)
+    with pytest.raises(RuntimeError, match="nothing to shard"):
+        qdist.check_shardable([Q, torch.zeros(3), torch.ones(1, 3), torch.ones(1), e, e], 8, 2)
+    qdist.check_shardable([Q, torch.zeros(8, 3), torch.ones(1, 3), torch.ones(1), e, e], 8, 2)
