@@ -348,7 +348,8 @@ QPX_DEV void tsweep_body(const Block& blk, const PrefactorArgs<double>& a, int q
                       : stage[(J * (J + 1) / 2 + I) * 256 + (j & 15) * 16 + (i & 15)];
     };
     // (rows dealt over the threads' high part, columns over the low part: no integer divisions in the loops)
-    const int cj = blk.tid & 127, ci = blk.tid >> 7, di = nt >> 7;
+    // (only whole groups of 128 threads take part: 448 threads = 3 groups, the last 64 threads sit these loops out)
+    const int ci = blk.tid >> 7, di = nt >> 7, cj = ci < di ? (blk.tid & 127) : (1 << 30);
     if (cj < n) {
         for (int i = ci; i < n; i += di) F[lay.Kneg + (size_t)i * n + cj] = pivot_elem(i, cj);
         for (int i = ci; i < q; i += di) F[lay.NTn + (size_t)i * n + cj] = pivot_elem(oA + i, cj);
