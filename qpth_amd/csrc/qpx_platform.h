@@ -39,18 +39,6 @@ struct Block {
     // scalar branches (the compiler cannot see that tid >> 6 is wave-uniform)
     QPX_DEV int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
 
-    // The SIMD (0 .. 3) of the CU this wave runs on: HW_ID bits 5:4.  The four waves of a 256-thread workgroup land
-    // on the four SIMDs in the cyclic order 0 -> 2 -> 1 -> 3 from a start that differs between the workgroups of
-    // a CU (profiles/r03a_probes_and_phases.txt), so the wave index says nothing about which waves share a SIMD.
-    QPX_DEV int simd_id() const
-    {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        return (int)((hw >> 4) & 3u);
-    }
-    // *word |= bits, word in LDS (atomic)
-    QPX_DEV void lds_or(int* word, int bits) const { __hip_atomic_fetch_or(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
     // workgroup barrier; LDS and global writes of the workgroup made before it are visible after.
     // The explicit wait is load-bearing: hipcc (ROCm 7.2) dropped the `s_waitcnt lgkmcnt(0)`
     // that belongs to __syncthreads() on the back-edge of the Cholesky column loop (every other
@@ -145,15 +133,15 @@ struct Block {
         }
     }
 
-    // the value lane (GK, c) holds, in every lane (g, c), g = 0 .. 3 (rows of 16 lanes): gfx950's two lane-swap
-    // instructions.  v_permlane32_swap(x, y) exchanges rows 2, 3 of x with rows 0, 1 of y; v_permlane16_swap(x, y)
+    // the value lane (GK, c) holds, in every lane (g, c), g = 0 .. 3 (rows of 16 lanes).  Default: ds_bpermute (the LDS
+    // crossbar, no LDS memory).  -DQPX_GRP_BCAST_SWAPS: gfx950's two lane-swap instructions (the round-2 default):  v_permlane32_swap(x, y) exchanges rows 2, 3 of x with rows 0, 1 of y; v_permlane16_swap(x, y)
     // exchanges the odd rows of x with the even rows of y -- applied to two copies of the value they leave one
     // register with the lower (even) rows everywhere and one with the upper (odd) rows.  8 instructions per
-    // double, no LDS.  (-DQPX_GRP_BCAST_BPERMUTE: the same through ds_bpermute, kept for A/B.)
+    // double, no LDS.
     template <int GK> QPX_DEV double grp_bcast(double v) const
     {
         static_assert(GK >= 0 && GK < 4, "four rows of 16 lanes");
-#ifdef QPX_GRP_BCAST_BPERMUTE
+#ifndef QPX_GRP_BCAST_SWAPS          // ds_bpermute: two instructions; with the chain wave alone on its SIMD -1 % loop time (profiles/r03r)
         return __shfl(v, GK * 16 + (lane() & 15), kWave);
 #else
         typedef unsigned u2 __attribute__((ext_vector_type(2)));

@@ -19,9 +19,9 @@
 //     panel k+1 WHILE the three tile-owning waves stream panel k's trailing updates (look-ahead by one panel: the
 //     16 x 16 pivot block is a serial chain of ~3000 cycles, the trailing update of a panel ~2500 cycles of matrix
 //     instructions per wave, and in the first form they ran one after the other), and it does the O(m) vector work
-//     of the interior-point loop.  Which wave that is, is decided by the SIMD it runs on (Pos::assign): an f64 MFMA
-//     holds its SIMD's vector ALU for the whole instruction, so a serial chain must not share a SIMD with a matrix
-//     stream -- the two workgroups of a CU put their chain waves on the same SIMD and their tile waves on the others.
+//     of the interior-point loop.  (An f64 MFMA holds its SIMD's vector ALU for the whole instruction: a serial chain
+//     beside a matrix stream of its OWN workgroup would crawl.  The four waves of a workgroup sit on four different
+//     SIMDs, so it never does; what it shares a SIMD with is a wave of the CU's other workgroup.)
 // Tile rows are dealt round-robin from the bottom over the NWM tile-owning waves: wave w owns rows
 // I_p = NBL-1 - p NWM - (w or NWM-1-w, alternating), p = 0 .. NPOS-1 ("positions"), and keeps tile (I_p, J) in
 // register slot slot(p, J) -- a static index for static (p, J); which row a position is, is a
@@ -86,10 +86,12 @@ QPX_LAYOUT_HD constexpr int tile_union_chain(int nbl, int nwm)      // chain-wav
 {
     return tile_union(nbl, nwm) > 2 * nbl * 256 ? tile_union(nbl, nwm) : 2 * nbl * 256;
 }
+// chain-wave form, behind the row buffer: S2 (256: the diagonal tile of the next pivot block but one)
+constexpr int kChainExtra = 256;
 QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nwm, bool chain = false)
 {
     return (size_t)16 * tile_xs(nbl) + 2 * 16 * 18 + 2 + (chain ? tile_union_chain(nbl, nwm) : tile_union(nbl, nwm)) +
-           16 * (size_t)nbl + (chain ? 256 : 0);
+           16 * (size_t)nbl + (chain ? kChainExtra : 0);
 }
 
 template <int NBL, int NW, bool CH = false> struct TileMat {
@@ -132,27 +134,12 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
               c(blk.lane() & 15), chain(CH && blk.uniform(blk.wave()) == 0)
         {
         }
-        // Chain-wave form: the role follows the SIMD the wave runs on -- SIMD 0 hosts the chain wave, SIMDs 1 .. 3 the
-        // tile waves -- provided the four waves of this workgroup really sit on four different SIMDs (observed for
-        // every workgroup of every launch on MI355X, profiles/r03a; nothing promises it, so it is checked: each wave
-        // sets its SIMD's bit in an LDS word).  Otherwise, and in the emulation, the role is the wave index.
-        // `word` is an LDS int the caller does not use before its next barrier.
-        QPX_DEV void assign(const Block& blk, int* word)
-        {
-            if constexpr (CH && NW == 4) {
-                const int simd = blk.simd_id();
-                if (blk.tid == 0) *word = 0;
-                blk.sync();
-                if (lane == 0) blk.lds_or(word, 1 << simd);
-                blk.sync();
-                const int mask = *word;
-                blk.sync();
-                if (blk.uniform(mask) == 15) {
-                    chain = simd == 0;
-                    w = simd - 1;
-                }
-            }
-        }
+        // Chain-wave form: wave 0 is the chain wave.  (Round 3 first assigned the roles by the SIMD a wave runs on
+        // -- s_getreg HW_ID -- so that the chain waves of the two workgroups of a CU shared SIMD 0 and never sat beside
+        // the other workgroup's MFMA streams; by wave index they land on different SIMDs, each beside one tile wave of
+        // the other QP.  Same box, C2: 0.5349 vs 0.5327 ms -- no difference, so the simpler rule stays:
+        // profiles/r03a (placement probe), r03q (A/B).)
+        QPX_DEV void assign(const Block&, int*) {}
         // the wave that does the O(m) vector work of the interior-point loop
         QPX_DEV bool lead(const Block& blk) const { return CH ? chain : blk.wave() == 0; }
         QPX_DEV bool is_chain() const { return CH && chain; }
@@ -219,7 +206,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     static constexpr int kRed = kPart + NWM * NBL * 64, kBT = kPart, kAT = kBT + NBL * 256;
     static constexpr int kRow = kPart + (CH ? tile_union_chain(NBL, NWM) : tile_union(NBL, NWM));
     static constexpr int kS2 = kRow + MP;
-    QPX_LAYOUT_HD static size_t scratch_elems() { return (size_t)kRow + MP + (CH ? 256 : 0); }
+    QPX_LAYOUT_HD static size_t scratch_elems() { return (size_t)kRow + MP + (CH ? kChainExtra : 0); }
     static QPX_DEV void sync(const Block& blk)
     {
         if (NW == 1) blk.wave_sync();
@@ -920,6 +907,13 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #endif
         return (int)flag[0];
     }
+    // (A form of the chain-wave factorisation WITHOUT workgroup barriers between chain and tile waves -- LDS words
+    // signalling "W_k is ready" one way and "the inputs of pivot block k are ready" the other, the tile waves keeping a
+    // counter barrier of their own, so that the chain wave never waits for the operand tiles -- was built and measured
+    // in round 3: +7 % loop time (0.560 vs 0.523 ms at C2, profiles/r03s_ab_async_chain.txt).  The tile waves, not the
+    // chain wave, are the longer side of a panel (operand tiles + nine tile updates + publication ~ 4 700 cycles against
+    // ~4 100 for pivot block + look-ahead), so taking the chain wave off their barriers buys nothing and the polling
+    // costs a little.  Removed.)
     struct PanelOf { int kmax, sign; };
     template <int ROLE>
     static QPX_DEV bool ldl_inv_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int m)

@@ -56,12 +56,6 @@ struct EmuShared {
     double* xv;                    // 16 doubles per thread (row_rank1: a whole register row in one round)
 };
 
-inline int emu_simd_rot()
-{
-    const char* e = std::getenv("QPX_EMU_SIMD_ROT");
-    return e ? std::atoi(e) : 0;
-}
-
 struct Block {
     int tid;
     int nt;
@@ -71,17 +65,6 @@ struct Block {
     int wave() const { return tid >> 6; }
     int nwaves() const { return nt >> 6; }
     int uniform(int v) const { return v; }
-    // QPX_EMU_SIMD_ROT=k: wave w reports SIMD (w + k) % 4, as a workgroup whose first wave landed on SIMD k (the wave ->
-    // role assignment of the tile kernels' chain-wave form); default: the wave index
-    int simd_id() const { return (wave() + emu_simd_rot()) & 3; }
-    void lds_or(int* word, int bits) const
-    {
-#ifdef QPX_EMU_PTHREADS
-        __atomic_fetch_or(word, bits, __ATOMIC_RELAXED);
-#else
-        *word |= bits;
-#endif
-    }
 #ifdef QPX_EMU_PTHREADS
     void sync() const { pthread_barrier_wait(&sh->block_bar); }
     void wave_sync() const { pthread_barrier_wait(&sh->wave_bar[wave()]); }

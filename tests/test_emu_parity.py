@@ -214,14 +214,12 @@ def test_every_loop_kernel_form(variant, shape):
             assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
-# Round 3: the chain-wave form of the four-wave tile kernels (the default for 65 <= nineq <= 112), its run-time role
-# assignment (which wave is the chain wave follows the SIMD a wave lands on: QPX_EMU_SIMD_ROT rotates that), the same
-# kernels without the chain wave (+16384) and the opt-in pre-factorisation on matrix-core tiles (+32768, qpx_tsweep.h).
-@pytest.mark.parametrize("variant,rot", [(0, 0), (0, 1), (0, 2), (0, 3), (16384, 0), (32768, 0), (32768 + 16384, 0)])
+# Round 3: the chain-wave form of the four-wave tile kernels (the default for 65 <= nineq <= 112), the same kernels
+# without the chain wave (+16384) and the opt-in pre-factorisation on matrix-core tiles (+32768, qpx_tsweep.h).
+@pytest.mark.parametrize("variant", [0, 16384, 32768, 32768 + 16384])
 @pytest.mark.parametrize("shape", [(2, 30, 100, 0), (2, 20, 70, 3), (1, 100, 112, 0), (1, 10, 81, 0)])
-def test_chain_wave_form_and_tile_sweep(monkeypatch, variant, rot, shape):
+def test_chain_wave_form_and_tile_sweep(variant, shape):
     B, n, m, q = shape
-    monkeypatch.setenv("QPX_EMU_SIMD_ROT", str(rot))
     arrs = problems.prof_qp(B, n, m, q, seed=11)
     dl = np.random.RandomState(5).randn(B, n)
     xr, _, _, _, grads_ref, _ = orc.qp_forward_backward(*arrs, dl, per_qp=True, stall_policy=(1 if B == 1 else 2))
