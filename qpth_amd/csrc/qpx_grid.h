@@ -24,6 +24,16 @@
 
 namespace qpx {
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a compile-time constant
+template <int I0, int N, class F> QPX_DEV void static_for_(F&& f)
+{
+    if constexpr (I0 < N) {
+        f(std::integral_constant<int, I0>{});
+        static_for_<I0 + 1, N>(f);
+    }
+}
+template <int N, class F> QPX_DEV void static_for(F&& f) { static_for_<0, N>(f); }
+
 constexpr int gtri(int x) { return x * (x + 1) / 2; }
 constexpr int gidx(int li, int lj) { return li * (li + 1) / 2 + lj; }   // li >= lj
 
@@ -468,21 +478,164 @@ QPX_DEV int sweep_step(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)]
     return 0;
 }
 
+// FOUR pivots at once (k0 .. k0 + 3, k0 = 16 KB + 4 gq): the sweep of the pivot BLOCK P = E(k0 .. k0+3, k0 .. k0+3),
+//   E_ij -= (C P^-1 C^T)_ij  for i, j outside the block,   E_i,P = (C P^-1)_i,   E_PP = -P^-1,     C = columns k0 .. k0+3
+// -- exactly what four rank-1 steps compose to, with two barriers and one serial chain (publish -> barrier -> reciprocals)
+// per four pivots instead of four: one pivot of the rank-1 form cost ~2 400 cycles with two QPs per CU, against ~830
+// for its 26 LDS reads and 91 FMAs per thread (profiles/r03a: the sweep was 74 % of the pre-factorisation).
+//   A  the owners publish the four columns (from the LOWER triangle only, as the rank-1 step: column k0+t below its
+//      pivot, row k0+t left of it)                                                              -- barrier 1
+//   B  every thread sweeps the 4 x 4 block P in registers (-> -P^-1, the same arithmetic in every thread, so the
+//      failure decision is uniform) and thread i < MA forms row i of U = C P^-1 -> LDS          -- barrier 2
+//   C  four rank-1 updates E -= U_t C_t^T back to back (no barrier between them: the LDS reads of one run beside the
+//      FMAs of the previous), rows and columns of the block masked out of them; then the block's own rows and columns
+//      are ASSIGNED (U, -P^-1), never formed through the update (see sweep_step).
+// C is double-buffered by the parity of gq (a thread may publish group gq + 1 while another still reads group gq).
+template <class T, int NBL, int KB>
+QPX_DEV int sweep_group4(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)], T* cbuf2, T* ubuf, T* pwbuf, int gq, int npos)
+{
+    constexpr int GS = 16, MA = GS * NBL;
+    const int k0 = GS * KB + 4 * gq;
+    T* C = cbuf2 + (gq & 1) * 4 * MA;            // C[t * MA + i] = E(i, k0 + t)
+    const bool bin = (g.b >> 2) == gq, ain = (g.a >> 2) == gq;      // this thread's column / row index (within a block) is one of the four
+    const int tb = g.b & 3, sa = g.a & 3;
+    // ---- A
+    if (bin) {
+#pragma unroll
+        for (int li = KB; li < NBL; ++li) {
+            const int i = GS * li + g.a;
+            if (i > k0 + tb) C[tb * MA + i] = E[gidx(li, KB)];
+        }
+    }
+    if (ain) {
+#pragma unroll
+        for (int lj = 0; lj <= KB; ++lj) {
+            const int j = GS * lj + g.b;
+            if (j < k0 + sa) C[sa * MA + j] = E[gidx(KB, lj)];
+        }
+        if (bin && sa == tb) C[sa * MA + k0 + sa] = E[gidx(KB, KB)];
+    }
+    GridPos<GS>::sync(blk);
+    // ---- B  One entry of P per lane -- lane 4 s + t of every row of 16 lanes holds P[s][t]; a thread-private copy of
+    // the block would be thirty more registers beside the 91 matrix entries of the largest instantiation -- swept by
+    // lane exchanges, the same arithmetic in every row of lanes and every wave (so the failure decision is uniform);
+    // the result, -P^-1, goes through an LDS copy of the wave's own.
+    const int ln = blk.lane(), ps = (ln >> 2) & 3, pt = ln & 3;
+    T pe = C[pt * MA + k0 + ps];
+    int fail = 0;
+    static_for<4>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        // row t of the block through scalar registers (four readlanes), column t through a DPP quad broadcast: no LDS
+        // crossbar in the chain of the four pivots
+        const T r0 = blk.bcast(pe, 4 * t), r1 = blk.bcast(pe, 4 * t + 1), r2 = blk.bcast(pe, 4 * t + 2), r3 = blk.bcast(pe, 4 * t + 3);
+        const T d = t == 0 ? r0 : (t == 1 ? r1 : (t == 2 ? r2 : r3));
+        const bool okp = (k0 + t < npos) ? (d > T(0)) : (d < T(0));
+        if (fail == 0 && (!okp || !finite_(d))) fail = (k0 + t < npos) ? QPX_ST_Q_NOT_SPD : QPX_ST_A_RANK;
+        const T r = rcp_(d);
+        const T pit = blk.template quad_bcast<t>(pe);                       // P[s][t]
+        const T ptj = pt == 0 ? r0 : (pt == 1 ? r1 : (pt == 2 ? r2 : r3));  // P[t][j]
+        const T lm = pit * r;
+        pe = (ps == t) ? ((pt == t) ? -r : ptj * r) : ((pt == t) ? lm : fma_(-lm, ptj, pe));
+    });
+    if (fail) return fail;
+    const T pm = blk.shfl_xor(pe, (4 * ps + pt) ^ (4 * pt + ps));
+    pe = ps >= pt ? pe : pm;                                 // symmetric to the bit: the lower triangle's values
+    T* Pw = pwbuf + 16 * blk.uniform(blk.wave());
+    if (ln < 16) Pw[ln] = pe;
+    blk.wave_sync();
+    const T pv = Pw[4 * sa + tb];                            // this thread's entry of -P^-1, if it holds one
+    if (g.tid < MA) {
+        T cs[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cs[s] = C[s * MA + g.tid];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            T u = T(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) u = fma_(-cs[s], Pw[4 * s + t], u);      // Pw holds -P^-1
+            ubuf[t * MA + g.tid] = u;
+        }
+    }
+    GridPos<GS>::sync(blk);
+    // ---- C
+    const T ma = ain ? T(0) : T(1), mb = bin ? T(0) : T(1);               // the block's own rows / columns take no update
+#pragma unroll 1                      // (unrolled, the four updates' operands are all fetched up front: 1.48 ms instead of 0.158 at C2, spills)
+    for (int t = 0; t < 4; ++t) {
+        const T* Ut = ubuf + t * MA;
+        const T* Ct = C + t * MA;
+        T vr[NBL];
+#pragma unroll
+        for (int l = 0; l < NBL; ++l) vr[l] = Ut[GS * l + g.a] * (l == KB ? ma : T(1));
+        // (one column operand ahead, no further: left to itself the scheduler fetches all NBL of them up front, and the
+        // largest instantiation has no registers for that beside its 91 matrix entries)
+        T y = Ct[g.b] * (0 == KB ? mb : T(1));
+#pragma unroll
+        for (int lj = 0; lj < NBL; ++lj) {
+            T yn = T(0);
+            if (lj + 1 < NBL) yn = Ct[GS * (lj + 1) + g.b] * (lj + 1 == KB ? mb : T(1));
+#pragma unroll
+            for (int li = lj; li < NBL; ++li) E[gidx(li, lj)] = fma_(-vr[li], y, E[gidx(li, lj)]);
+            QPX_SCHED_FENCE();
+            y = yn;
+        }
+    }
+    // (the addresses of the loads below are made opaque HERE: hoisted above the four updates, the 2 x NBL values they
+    // fetch sat in registers through them -- 107 spilled registers at NBL = 13)
+    int ua = g.a, ub = g.b;
+    QPX_LAUNDER_V(ua);
+    QPX_LAUNDER_V(ub);
+    if (bin) {                                   // columns k0 + tb: (i, k0 + tb) = U_i,tb; inside the block: -P^-1
+#pragma unroll
+        for (int li = KB; li < NBL; ++li) {
+            const T u = ubuf[tb * MA + GS * li + ua];
+            E[gidx(li, KB)] = (li == KB && ain) ? pv : u;
+        }
+    }
+    if (ain) {                                   // rows k0 + sa, columns outside the block: (k0 + sa, j) = U_j,sa
+        // (one store per element, the block's own entry kept BY VALUE: the same store under two branches is merged
+        // into one store through a pointer, and a register array whose address is taken lives in scratch memory)
+#pragma unroll
+        for (int lj = 0; lj <= KB; ++lj) {
+            const T u = ubuf[sa * MA + GS * lj + ub];
+            E[gidx(KB, lj)] = (lj == KB && bin) ? E[gidx(KB, lj)] : u;
+        }
+    }
+    return 0;
+}
+
 template <class T, int NBL, int KB> struct SweepBlocks {
-    static QPX_DEV int run(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, int npos, int npiv)
+    static QPX_DEV int run(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)], T* vec2, T* dsl, T* cbuf2, T* ubuf, int npos, int npiv)
     {
         if (16 * KB >= npiv) return 0;
+        constexpr int GSMA = 16 * NBL;
         const int kend = (npiv - 16 * KB < 16) ? (npiv - 16 * KB) : 16;
+        int ka = 0;
+#ifndef QPX_AB_RANK1_SWEEP
+        // Four pivots per barrier pair where a CU holds at most two or three workgroups (NBL >= 10: <= 256 registers
+        // per thread at 45 .. 91 matrix entries): there the barrier and the publish -> reciprocal chain of every pivot
+        // are exposed.  Measured on one MI355X, pre-factorisation alone, rank-1 -> groups of four: C2 (NBL 13) 0.166 ->
+        // 0.158 ms, C3 (NBL 10) 0.139 -> 0.123 ms; at NBL 8 with eight workgroups per CU (B = 2048, n = m = 64) the
+        // other workgroups already hide those latencies and the groups' extra work (U, the assignments) costs 0.189 ->
+        // 0.196 ms: rank-1 stays there (profiles/r03w).
+        if constexpr (NBL >= 10) {
 #pragma unroll 1
-        for (int ka = 0; ka < kend; ++ka) {
+            for (int gq = 0; 4 * gq + 4 <= kend; ++gq) {
+                const int f = sweep_group4<T, NBL, KB>(blk, g, E, cbuf2, ubuf, ubuf + 4 * GSMA, gq, npos);
+                if (f) return f;
+                ka = 4 * gq + 4;
+            }
+        }
+#endif
+#pragma unroll 1
+        for (; ka < kend; ++ka) {                // (the last n + q mod 4 pivots: one at a time)
             const int f = sweep_step<T, NBL, KB>(blk, g, E, vec2, dsl, ka, npos);
             if (f) return f;
         }
-        return SweepBlocks<T, NBL, KB + 1>::run(blk, g, E, vec2, dsl, npos, npiv);
+        return SweepBlocks<T, NBL, KB + 1>::run(blk, g, E, vec2, dsl, cbuf2, ubuf, npos, npiv);
     }
 };
 template <class T, int NBL> struct SweepBlocks<T, NBL, NBL> {
-    static QPX_DEV int run(const Block&, const GridPos<16>&, T (&)[gtri(NBL)], T*, T*, int, int) { return 0; }
+    static QPX_DEV int run(const Block&, const GridPos<16>&, T (&)[gtri(NBL)], T*, T*, T*, T*, int, int) { return 0; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -550,7 +703,9 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
     }
     QPX_PROF(1)
     // ---- sweep pivots 0 .. n+q-1 (static block index via template recursion, see SweepBlocks)
-    const int fail = SweepBlocks<T, NBL, 0>::run(blk, g, E, vec2, dsl, n, nq);
+    // (the four-pivot groups' buffers -- two generations of four columns, one of U, a 4 x 4 block per wave:
+    // 12 MA + 64 <= 256 NBL -- share `red`, which only the column sums above used)
+    const int fail = SweepBlocks<T, NBL, 0>::run(blk, g, E, vec2, dsl, red, red + 8 * MA, n, nq);
     GridPos<GS>::sync(blk);
     if (fail) {
         for (size_t e = blk.tid; e < lay.total; e += NT) F[e] = T(0);

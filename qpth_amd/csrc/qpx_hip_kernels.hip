@@ -97,7 +97,8 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream)
     template int launch_kkt<QPX_TU_REAL, NS, L, false>(const KktArgs<QPX_TU_REAL>&, size_t, void*); \
     template int launch_kkt<QPX_TU_REAL, NS, L, true>(const KktArgs<QPX_TU_REAL>&, size_t, void*);
 #elif QPX_TU_KERNEL == 5
-template <class T, int NBL> __global__ __launch_bounds__(256) void k_sweep(PrefactorArgs<T> a)
+// (at least two workgroups per CU -- <= 256 registers -- at every size: the largest instantiation holds 91 matrix entries per thread)
+template <class T, int NBL> __global__ __launch_bounds__(256, 2) void k_sweep(PrefactorArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};

@@ -97,6 +97,21 @@ struct Block {
         return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false));
     }
 
+    // value of `v` held by lane K of this lane's QUAD (lanes 4 j .. 4 j + 3): DPP quad_perm [K, K, K, K]
+    template <int K> QPX_DEV double quad_bcast(double v) const
+    {
+        static_assert(K >= 0 && K < 4, "quad of 4 lanes");
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), K * 0x55, 0xF, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), K * 0x55, 0xF, 0xF, false);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    template <int K> QPX_DEV float quad_bcast(float v) const
+    {
+        static_assert(K >= 0 && K < 4, "quad of 4 lanes");
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xF, 0xF, false));
+    }
+
     // value of `v` held by lane K of this lane's row of 16 lanes: DPP row_newbcast, the one DPP pattern the
     // f64 ALU of gfx90a+ takes (v_mov_b64_dpp; the compiler folds it into v_rcp_f64_dpp and friends)
     template <int K> QPX_DEV double row_bcast(double v) const

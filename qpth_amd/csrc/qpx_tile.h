@@ -64,15 +64,6 @@ static __device__ unsigned long long qpx_chain_prof[20];
 
 namespace qpx {
 
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a compile-time constant
-template <int I0, int N, class F> QPX_DEV void static_for_(F&& f)
-{
-    if constexpr (I0 < N) {
-        f(std::integral_constant<int, I0>{});
-        static_for_<I0 + 1, N>(f);
-    }
-}
-template <int N, class F> QPX_DEV void static_for(F&& f) { static_for_<0, N>(f); }
 
 // row stride of the panel's X rows (17 mod 32 doubles) and size of the region the mat-vec partials share with the
 // operand tiles of the factorisation (nwm = the waves that own tiles)

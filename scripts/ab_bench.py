@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of two builds of the library ON THE SAME BOX (boxes of the pool differ by ~6 % in clocks):
-ab_bench.py <libA.so>[:variant] <libB.so>[:variant] ... [B n m q]  -- fwd+bwd ms per step and the loop kernel's ms,
+ab_bench.py <libA.so>[:variant] <libB.so>[:variant] ... [B n m q]  -- fwd+bwd ms per step, the loop kernel's ms and the pre-factorisation's (KKTFactors.build),
 alternating; `:variant` = the value qpx_set_ipm_variant gets for that entry (default $QPX_VARIANT or 0)."""
 import os
 import sys
@@ -45,6 +45,12 @@ for rep in range(3):
         for _ in range(20):
             fac.ipm(p.detach(), h, b)
         e1.record(); torch.cuda.synchronize()
-        print("%-40s step %.4f ms   loop kernel %.4f ms" % (os.path.basename(name), step, e0.elapsed_time(e1) / 20))
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        for _ in range(20):
+            KKTFactors.build(Q, G, A, B)
+        f1.record(); torch.cuda.synchronize()
+        print("%-40s step %.4f ms   loop kernel %.4f ms   pre-factorisation %.4f ms" %
+              (os.path.basename(name), step, e0.elapsed_time(e1) / 20, f0.elapsed_time(f1) / 20))
         lib.dll.qpx_set_ipm_variant(0)
         _lib.set_test_backend(None)

@@ -91,6 +91,8 @@ struct Block {
     float bcast(float v, int src) const { return exchange(v, src); }
     double bcast(double v, int src) const { return exchange(v, src); }
     int bcast(int v, int src) const { return exchange(v, src); }
+    template <int K> double quad_bcast(double v) const { return exchange(v, (lane() & ~3) | K); }
+    template <int K> float quad_bcast(float v) const { return exchange(v, (lane() & ~3) | K); }
     template <int MASK> double xor16(double v) const { return exchange(v, lane() ^ MASK); }
     template <int MASK> float xor16(float v) const { return exchange(v, lane() ^ MASK); }
 
