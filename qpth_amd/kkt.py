@@ -97,7 +97,8 @@ class KKTFactors:
         # on its own thread)
         self.variant = int(self.lib.dll.qpx_get_ipm_variant())
         # does the kernel family that serves this size refine KKT solves in the kernel (qpx_factor_solve_kkt(..., refine))?
-        self.refine_ok = bool(self.lib.dll.qpx_refine_supported(code, self.n, self.m, self.q))
+        # (a pre-v5 build loaded non-strictly by scripts/ab_bench.py has no such symbol: it ignored `refine` where it could not refine)
+        self.refine_ok = bool(self.lib.dll.qpx_refine_supported(code, self.n, self.m, self.q)) if hasattr(self.lib.dll, "qpx_refine_supported") else True
         share_ok = bool(self.lib.dll.qpx_can_share_factors(code, self.n, self.m, self.q))
         self.shared = B > 1 and share_ok and _is_shared(Q, B) and _is_shared(G, B) and _is_shared(A, B)
         nblob = 1 if self.shared else B
