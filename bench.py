@@ -91,6 +91,8 @@ def kernel_source_digest():
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "qpth_amd", "csrc")
     for name in sorted(os.listdir(d)):
+        if name == "qpx_bench.hip":       # the micro-benchmarks (libqpx_bench.so): not part of the product library
+            continue
         if name.endswith((".h", ".hip", ".inc")) or name == "Makefile":
             text = open(os.path.join(d, name), "r", errors="replace").read()
             if name != "Makefile":

@@ -160,6 +160,26 @@ template <int NACC> __global__ __launch_bounds__(64) void k_mfma_f64(double* out
     out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = sum;
     if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (4.0 * NACC * reps);
 }
+// 10b. v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction, ONE accumulator register per lane:
+// 256 multiply-adds against the 1024 of the 16x16x4 form): what a tile row with four real rows of sixteen would use
+template <int NACC> __global__ __launch_bounds__(64) void k_mfma_f64_4x4(double* out, const double* in, int reps)
+{
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = in[threadIdx.x] + i;
+    const double a = in[threadIdx.x + 128] * 1e-3, bb = in[threadIdx.x + 192] * 1e-3;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, acc[i], 0, 0, 0);
+    }
+    double sum = 0;
+    for (int i = 0; i < NACC; ++i) sum += acc[i];
+    long long t1 = clock64();
+    out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = sum;
+    if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (4.0 * NACC * reps);
+}
 template <int NACC> __global__ __launch_bounds__(64) void k_vfma_tile(double* out, const double* in, int reps)
 {
     double acc[NACC][4];
@@ -393,6 +413,8 @@ extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, co
     case 21: hipLaunchKernelGGL(k_mfma_f64<1>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 22: hipLaunchKernelGGL(k_mfma_f64<2>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 23: hipLaunchKernelGGL(k_vfma_tile<8>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 24: hipLaunchKernelGGL(k_mfma_f64_4x4<8>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 25: hipLaunchKernelGGL(k_mfma_f64_4x4<1>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 30: hipLaunchKernelGGL(k_pivot_block<0>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 31: hipLaunchKernelGGL(k_pivot_block<1>, dim3(blocks), dim3(320), 0, s, out, in, reps); break;
     case 32: hipLaunchKernelGGL(k_pivot_block<2>, dim3(blocks), dim3(320), 0, s, out, in, reps); break;

@@ -13,11 +13,12 @@ dev = torch.device("cuda:0")
 out = torch.zeros(20480 + 4096, dtype=torch.float64, device=dev)
 inp = torch.rand(4096, dtype=torch.float64, device=dev) * 0.5 + 0.75
 names = {20: "mfma f64 16x16x4, 8 accumulators", 22: "mfma f64 16x16x4, 2 accumulators", 21: "mfma f64 16x16x4, dependent chain",
-         23: "rank-4 tile update by 16 vector FMAs"}
+         23: "rank-4 tile update by 16 vector FMAs", 24: "mfma f64 4x4x4 (4 blocks), 8 accumulators",
+         25: "mfma f64 4x4x4 (4 blocks), dependent chain"}
 for blocks in (1, 512, 1024, 2048):
-    for which in (20, 22, 21, 23):
+    for which in (20, 22, 21, 23, 24, 25):
         out.zero_()
         assert lib.qpx_bench(which, blocks, 500, 0, out.data_ptr(), inp.data_ptr(), None) == 0
         torch.cuda.synchronize()
         t = out[4096:4096 + blocks].cpu().numpy()
-        print("%5d waves  %-40s ticks per tile update: mean %7.1f min %7.1f max %7.1f" % (blocks, names[which], t.mean(), t.min(), t.max()))
+        print("%5d waves  %-42s ticks per instruction (23: per tile update): mean %7.1f min %7.1f max %7.1f" % (blocks, names[which], t.mean(), t.min(), t.max()))
