@@ -180,6 +180,22 @@ template <int NACC> __global__ __launch_bounds__(64) void k_mfma_f64_4x4(double*
     out[20480 + (blockIdx.x & 63) * 64 + threadIdx.x] = sum;
     if (threadIdx.x == 0) out[4096 + blockIdx.x] = double(t1 - t0) / (4.0 * NACC * reps);
 }
+// 10c. the lane layout of v_mfma_f64_4x4x4_4b_f64, decoded with powers of two: out[x * 64 + lane] for x = 0 .. 17:
+//   x = 16: A = 2^(lane % 16), B = 1          -> D = sum over k of A: which A lanes feed each D lane
+//   x = 17: A = 1, B = 2^(lane % 16)          -> which B lanes feed each D lane
+//   x < 16: A = 2^(lane % 16), B = 1 in lanes with lane % 16 == x only (0 elsewhere) -> the A lane that meets B lane x
+__global__ __launch_bounds__(64) void k_mfma4_layout(double* out, const double* in, int reps)
+{
+    const int lane = threadIdx.x;
+    const double p2 = double(1 << (lane & 15));
+    for (int x = 0; x < 18; ++x) {
+        const double a = x == 17 ? 1.0 : p2;
+        const double b = x == 16 ? 1.0 : (x == 17 ? p2 : ((lane & 15) == x ? 1.0 : 0.0));
+        out[x * 64 + lane] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0);
+    }
+    // x = 18: blocks: A = 1 in block (lane / 16) == 0 only, B = 1 -> which D lanes see block 0's A
+    out[18 * 64 + lane] = __builtin_amdgcn_mfma_f64_4x4x4f64(lane < 16 ? 1.0 : 0.0, 1.0, 0.0, 0, 0, 0);
+}
 template <int NACC> __global__ __launch_bounds__(64) void k_vfma_tile(double* out, const double* in, int reps)
 {
     double acc[NACC][4];
@@ -413,6 +429,7 @@ extern "C" int qpx_bench(int which, int blocks, int reps, int m, double* out, co
     case 21: hipLaunchKernelGGL(k_mfma_f64<1>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 22: hipLaunchKernelGGL(k_mfma_f64<2>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 23: hipLaunchKernelGGL(k_vfma_tile<8>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
+    case 26: hipLaunchKernelGGL(k_mfma4_layout, dim3(1), dim3(64), 0, s, out, in, reps); break;
     case 24: hipLaunchKernelGGL(k_mfma_f64_4x4<8>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 25: hipLaunchKernelGGL(k_mfma_f64_4x4<1>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
     case 30: hipLaunchKernelGGL(k_pivot_block<0>, dim3(blocks), dim3(64), 0, s, out, in, reps); break;
