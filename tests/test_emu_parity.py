@@ -157,6 +157,28 @@ def test_not_spd_raises_like_the_reference():
             QPFunction(verbose=-1)(Q.unsqueeze(0), p, G, h, e, e)
 
 
+@pytest.mark.parametrize("shape", [(2, 100, 50, 10), (2, 60, 100, 6)])
+def test_sweep_by_groups_of_four_reports_breakdowns(shape):
+    """Round 3: at order n + q + m >= 145 the pre-factorisation sweeps four pivots per barrier pair (qpx_grid.h:
+    sweep_group4); a pivot that breaks down INSIDE a group -- a Q that is not SPD, an A without full row rank -- must
+    raise what the rank-1 sweep raises (batch.py:382-386, 419-423), and healthy QPs of the same sizes must still solve."""
+    B, n, m, q = shape
+    Q, p, G, h, A, b = [torch.tensor(x) for x in problems.prof_qp(B, n, m, q, seed=3)]
+    with emulated(256):
+        z = QPFunction(verbose=-1)(Q, p, G, h, A, b)
+        assert torch.isfinite(z).all()
+        Qb = Q.clone()
+        Qb[1] = -Qb[1]
+        with pytest.raises(RuntimeError, match="Cannot perform LU factorization on Q"):
+            QPFunction(verbose=-1, check_Q_spd=False)(Qb, p, G, h, A, b)
+        Ab = A.clone()
+        Ab[1, 5] = 0                            # a zero row of A in the middle of a group: its pivot is exactly 0
+        bb = b.clone()                          # (two EQUAL rows leave a pivot of rounding noise of either sign)
+        bb[1, 5] = 0
+        with pytest.raises(RuntimeError, match="full row rank"):
+            QPFunction(verbose=-1)(Q, p, G, h, Ab, bb)
+
+
 def test_verbose_trace_and_inaccuracy_warning():
     g = load_golden("c1_b8_n10_m5_f64")
     tq = tens([g[k] for k in ("Q", "p", "G", "h", "A", "b")], grad=False)
