@@ -368,19 +368,30 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // lanes): the pivot d_K is then lane K's dg in every group, so its reciprocal (the long chain: estimate + two
     // Newton steps) runs beside the lane swaps that copy column K from its group K / 4 to the other three.  Every
     // lane then updates its four columns with the pivot row from lane K of its own row of 16 lanes.
+    // (r3) The copy of column K to the other three lane groups used to sit ON the chain of the sixteen pivots (rank-1
+    // update of pivot K-1 -> select -> ds_bpermute, ~80 cycles -> multipliers -> rank-1 update of pivot K).  Now every
+    // group carries the NEXT pivot column `vn` itself: the copy of column K+1 as it stands is started at the top of
+    // pivot K, and pivot K's update is applied to the copy by one more multiply-add through the row broadcast -- the same
+    // operation, on the same values, as the owner's -- so that only the reciprocal chain links one pivot to the next.
     template <int K>
-    static QPX_DEV void pivot16(const Block& blk, const Pos& p, T (&a)[4], T& dg, T& myr)
+    static QPX_DEV void pivot16(const Block& blk, const Pos& p, T (&a)[4], T& dg, T& myr, T& vn)
     {
         constexpr int GK = K / 4, KK = K % 4;
         const T dk = blk.template row_bcast<K>(dg);
+        T raw[1] = {T(0)};
+        if constexpr (K < 14) raw[0] = blk.template grp_bcast<(K + 1) / 4>(a[(K + 1) % 4]);   // column K+1 before this pivot's update
         const T r = rcp_(dk);
         myr = p.lane == K ? r : myr;                             // (the pivots are checked together, after the block)
         if constexpr (K < 15) {
-            const T v = blk.template grp_bcast<GK>(p.c > K ? a[KK] : T(0));   // column K below the pivot, 0 above
+            const T v = p.c > K ? vn : T(0);                     // column K below the pivot, 0 above
             const T nl = -(v * r);                               // -l~
             blk.template row_rank1<K>(a, nl);
             a[KK] = p.g == GK ? nl : a[KK];                      // column K: assigned (see qpx_grid.h); 0 on and above the diagonal
             dg = fma_(nl, v, dg);                                // (moved in front of the rank-1 update: +1 % loop time, r03h)
+            if constexpr (K < 14) {
+                blk.template row_rank1<K>(raw, nl);              // raw[c] += raw[K] * nl[c]: column K+1 after this pivot
+                vn = raw[0];
+            }
         } else {
             a[KK] = p.g == GK ? T(0) : a[KK];
         }
@@ -401,22 +412,23 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
         T dg = S[p.c * SS + p.c], myr = T(1);
-        pivot16<0>(blk, p, a, dg, myr);
-        if (kmax > 1) pivot16<1>(blk, p, a, dg, myr);
-        if (kmax > 2) pivot16<2>(blk, p, a, dg, myr);
-        if (kmax > 3) pivot16<3>(blk, p, a, dg, myr);
-        if (kmax > 4) pivot16<4>(blk, p, a, dg, myr);
-        if (kmax > 5) pivot16<5>(blk, p, a, dg, myr);
-        if (kmax > 6) pivot16<6>(blk, p, a, dg, myr);
-        if (kmax > 7) pivot16<7>(blk, p, a, dg, myr);
-        if (kmax > 8) pivot16<8>(blk, p, a, dg, myr);
-        if (kmax > 9) pivot16<9>(blk, p, a, dg, myr);
-        if (kmax > 10) pivot16<10>(blk, p, a, dg, myr);
-        if (kmax > 11) pivot16<11>(blk, p, a, dg, myr);
-        if (kmax > 12) pivot16<12>(blk, p, a, dg, myr);
-        if (kmax > 13) pivot16<13>(blk, p, a, dg, myr);
-        if (kmax > 14) pivot16<14>(blk, p, a, dg, myr);
-        if (kmax > 15) pivot16<15>(blk, p, a, dg, myr);
+        T vn = blk.template grp_bcast<0>(a[0]);             // column 0, in every lane group
+        pivot16<0>(blk, p, a, dg, myr, vn);
+        if (kmax > 1) pivot16<1>(blk, p, a, dg, myr, vn);
+        if (kmax > 2) pivot16<2>(blk, p, a, dg, myr, vn);
+        if (kmax > 3) pivot16<3>(blk, p, a, dg, myr, vn);
+        if (kmax > 4) pivot16<4>(blk, p, a, dg, myr, vn);
+        if (kmax > 5) pivot16<5>(blk, p, a, dg, myr, vn);
+        if (kmax > 6) pivot16<6>(blk, p, a, dg, myr, vn);
+        if (kmax > 7) pivot16<7>(blk, p, a, dg, myr, vn);
+        if (kmax > 8) pivot16<8>(blk, p, a, dg, myr, vn);
+        if (kmax > 9) pivot16<9>(blk, p, a, dg, myr, vn);
+        if (kmax > 10) pivot16<10>(blk, p, a, dg, myr, vn);
+        if (kmax > 11) pivot16<11>(blk, p, a, dg, myr, vn);
+        if (kmax > 12) pivot16<12>(blk, p, a, dg, myr, vn);
+        if (kmax > 13) pivot16<13>(blk, p, a, dg, myr, vn);
+        if (kmax > 14) pivot16<14>(blk, p, a, dg, myr, vn);
+        if (kmax > 15) pivot16<15>(blk, p, a, dg, myr, vn);
 #pragma unroll
         for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = (4 * p.g + j < kmax) ? a[j] : T(0);
         if (p.lane < 16) rd[k0 + p.lane] = myr;
