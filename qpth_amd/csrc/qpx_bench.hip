@@ -232,8 +232,10 @@ template <int PARTNER> __global__ __launch_bounds__(PARTNER ? 320 : 64) void k_p
 {
     typedef TileMat<7, 4> TM;
     __shared__ volatile int done;
+    __shared__ double lines[5 * 32];                  // the pivot-row line of every wave (TileMat::pivot16)
     const Block b{(int)(threadIdx.x & 63), 64};
     const int wave = threadIdx.x >> 6;
+    double* line = lines + 32 * wave;
     if (threadIdx.x == 0) done = 0;
     __syncthreads();
     if (wave == 0) {
@@ -245,10 +247,11 @@ template <int PARTNER> __global__ __launch_bounds__(PARTNER ? 320 : 64) void k_p
             // a diagonally dominant symmetric block: row c, columns 4 g .. 4 g + 3
             for (int j = 0; j < 4; ++j) a[j] = (p.c == 4 * p.g + j ? 20.0 : 0.0) + in[(p.c * 16 + 4 * p.g + j + r) & 1023] + in[((4 * p.g + j) * 16 + p.c + r) & 1023];
             double dg = 20.0 + 2 * in[(p.c * 17 + r) & 1023], myr = 1.0;
-            TM::pivot16<0>(b, p, a, dg, myr); TM::pivot16<1>(b, p, a, dg, myr); TM::pivot16<2>(b, p, a, dg, myr); TM::pivot16<3>(b, p, a, dg, myr);
-            TM::pivot16<4>(b, p, a, dg, myr); TM::pivot16<5>(b, p, a, dg, myr); TM::pivot16<6>(b, p, a, dg, myr); TM::pivot16<7>(b, p, a, dg, myr);
-            TM::pivot16<8>(b, p, a, dg, myr); TM::pivot16<9>(b, p, a, dg, myr); TM::pivot16<10>(b, p, a, dg, myr); TM::pivot16<11>(b, p, a, dg, myr);
-            TM::pivot16<12>(b, p, a, dg, myr); TM::pivot16<13>(b, p, a, dg, myr); TM::pivot16<14>(b, p, a, dg, myr); TM::pivot16<15>(b, p, a, dg, myr);
+            double vn_a = b.template grp_bcast<0>(a[0]);        // column 0 in every lane group (TileMat::pivot_block)
+            TM::pivot16<0>(b, p, a, dg, myr, vn_a); TM::pivot16<1>(b, p, a, dg, myr, vn_a); TM::pivot16<2>(b, p, a, dg, myr, vn_a); TM::pivot16<3>(b, p, a, dg, myr, vn_a);
+            TM::pivot16<4>(b, p, a, dg, myr, vn_a); TM::pivot16<5>(b, p, a, dg, myr, vn_a); TM::pivot16<6>(b, p, a, dg, myr, vn_a); TM::pivot16<7>(b, p, a, dg, myr, vn_a);
+            TM::pivot16<8>(b, p, a, dg, myr, vn_a); TM::pivot16<9>(b, p, a, dg, myr, vn_a); TM::pivot16<10>(b, p, a, dg, myr, vn_a); TM::pivot16<11>(b, p, a, dg, myr, vn_a);
+            TM::pivot16<12>(b, p, a, dg, myr, vn_a); TM::pivot16<13>(b, p, a, dg, myr, vn_a); TM::pivot16<14>(b, p, a, dg, myr, vn_a); TM::pivot16<15>(b, p, a, dg, myr, vn_a);
             sum += a[0] + a[1] + a[2] + a[3] + myr;
         }
         long long t1 = clock64();
@@ -329,8 +332,10 @@ template <int MODE> __global__ __launch_bounds__(320) void k_pivot_pair(double* 
 {
     typedef TileMat<7, 4> TM;
     __shared__ volatile int done;
+    __shared__ double lines[5 * 32];                  // the pivot-row line of every wave (TileMat::pivot16)
     const Block b{(int)(threadIdx.x & 63), 64};
     const int wave = threadIdx.x >> 6;
+    double* line = lines + 32 * wave;
     if (threadIdx.x == 0) done = 0;
     __syncthreads();
     if (wave == 0 || (MODE == 1 && wave == 4)) {
@@ -342,10 +347,11 @@ template <int MODE> __global__ __launch_bounds__(320) void k_pivot_pair(double* 
             double a[4];
             for (int j = 0; j < 4; ++j) a[j] = (p.c == 4 * p.g + j ? 20.0 : 0.0) + in[(p.c * 16 + 4 * p.g + j + r) & 1023] + in[((4 * p.g + j) * 16 + p.c + r) & 1023];
             double dg = 20.0 + 2 * in[(p.c * 17 + r) & 1023], myr = 1.0;
-            TM::pivot16<0>(b, p, a, dg, myr); TM::pivot16<1>(b, p, a, dg, myr); TM::pivot16<2>(b, p, a, dg, myr); TM::pivot16<3>(b, p, a, dg, myr);
-            TM::pivot16<4>(b, p, a, dg, myr); TM::pivot16<5>(b, p, a, dg, myr); TM::pivot16<6>(b, p, a, dg, myr); TM::pivot16<7>(b, p, a, dg, myr);
-            TM::pivot16<8>(b, p, a, dg, myr); TM::pivot16<9>(b, p, a, dg, myr); TM::pivot16<10>(b, p, a, dg, myr); TM::pivot16<11>(b, p, a, dg, myr);
-            TM::pivot16<12>(b, p, a, dg, myr); TM::pivot16<13>(b, p, a, dg, myr); TM::pivot16<14>(b, p, a, dg, myr); TM::pivot16<15>(b, p, a, dg, myr);
+            double vn_a = b.template grp_bcast<0>(a[0]);        // column 0 in every lane group (TileMat::pivot_block)
+            TM::pivot16<0>(b, p, a, dg, myr, vn_a); TM::pivot16<1>(b, p, a, dg, myr, vn_a); TM::pivot16<2>(b, p, a, dg, myr, vn_a); TM::pivot16<3>(b, p, a, dg, myr, vn_a);
+            TM::pivot16<4>(b, p, a, dg, myr, vn_a); TM::pivot16<5>(b, p, a, dg, myr, vn_a); TM::pivot16<6>(b, p, a, dg, myr, vn_a); TM::pivot16<7>(b, p, a, dg, myr, vn_a);
+            TM::pivot16<8>(b, p, a, dg, myr, vn_a); TM::pivot16<9>(b, p, a, dg, myr, vn_a); TM::pivot16<10>(b, p, a, dg, myr, vn_a); TM::pivot16<11>(b, p, a, dg, myr, vn_a);
+            TM::pivot16<12>(b, p, a, dg, myr, vn_a); TM::pivot16<13>(b, p, a, dg, myr, vn_a); TM::pivot16<14>(b, p, a, dg, myr, vn_a); TM::pivot16<15>(b, p, a, dg, myr, vn_a);
             sum += a[0] + a[1] + a[2] + a[3] + myr;
         }
         long long t1 = clock64();

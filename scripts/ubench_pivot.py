@@ -8,7 +8,7 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(ROOT, "qpth_amd", "libqpx_bench.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "qpth_amd", sys.argv[1] if len(sys.argv) > 1 else "libqpx_bench.so"))
 lib.qpx_bench.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
 dev = torch.device("cuda:0")
 out = torch.zeros(20480 + 4096, dtype=torch.float64, device=dev)
