@@ -640,12 +640,25 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // update (rows above the panel accumulate the negated inverse of the swept block), the panel's own row becomes
     // (-D^-1 b_Ip)^T b_J instead of b_J.
     template <int W, int PP, bool kSweep>
-    static QPX_DEV void update_row(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr)
+    static QPX_DEV void update_row(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr, int mrows)
     {
         constexpr int I = rowof(PP, W);
         if constexpr (I >= 0) {
             const T* BT = scr + kBT;
             const T* AT = scr + kAT;
+            if constexpr (I >= NBL - 2 && NBL >= 4 && !kSweep) {      // (the chain-wave form serves 65 <= m <= 112: tile rows 5 and 6 can be part padding)
+                // The last tile rows hold the matrix's last rows and then padding (m = 100: four real rows of sixteen in
+                // tile row 6), and they are the widest: seven and six tiles, updated by every panel.  When it is part padding it is updated at
+                // four-row granularity with the four-block matrix instruction (v_mfma_f64_4x4x4_4b: register q of a tile
+                // += A_q B with the same B operands), and row blocks that are all padding get nothing -- their operand
+                // columns are zero.  (Everywhere else the 16x16x4 form stays: with full tiles the four-block form
+                // measured 6 % slower, profiles/r03x.)
+                const int nq = mrows - 16 * I >= 16 ? 4 : (mrows - 16 * I <= 0 ? 0 : (mrows - 16 * I + 3) >> 2);
+                if (I > Ip && nq < 4) {
+                    if (nq > 0) update_row_quads<PP, I>(blk, p, E, BT, AT, Ip, skip, zr, nq);
+                    return;
+                }
+            }
             if (I == Ip && !kSweep) {            // the panel's own rows are final
 #pragma unroll
                 for (int J = 0; J <= I; ++J)
@@ -696,13 +709,49 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             }
         }
     }
+    // tile row I (> Ip), row blocks 0 .. nq - 1 of every tile: a[q][s] = the scaled operand tile's entries
+    // (4 s + h, 4 q + j) in every block of four lanes of lane row h -- the A operand of the four-block instruction
+    template <int PP, int I>
+    static QPX_DEV void update_row_quads(const Block& blk, const Pos& p, Regs& E, const T* BT, const T* AT, int Ip, int skip, T zr, int nq)
+    {
+        const T* ATq = AT + I * 256 + (p.lane & ~15) + (p.lane & 3);
+        constexpr int G = 4;                         // tiles whose products are interleaved
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= nq) break;                      // (uniform)
+            T a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = ATq[s * 64 + 4 * q];
+#pragma unroll
+            for (int J0 = 0; J0 <= I; J0 += G) {
+                T b[G][4];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int J = J0 + j;
+                    if (J > I) continue;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[j][s] = BT[J * 256 + s * 64 + p.lane];
+                    if (J < I) E.e[slot(PP, J)][q] *= (J == Ip) ? zr : T(1);      // the panel's own column restarts from zero
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        const int J = J0 + j;
+                        if (J > I) continue;
+                        if (J == I && I == skip) continue;       // (the chain wave brings the next pivot block up to date itself)
+                        blk.mfma4x4x4(a[s], b[j][s], E.e[slot(PP, J)][q]);
+                    }
+            }
+        }
+    }
     template <int W, bool kSweep = false>
-    static QPX_DEV void update_rows(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr)
+    static QPX_DEV void update_rows(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr, int mrows)
     {
         // heaviest row last: its tiles are the ones the publish that follows does not read
-        if constexpr (NPOS > 2) update_row<W, 2, kSweep>(blk, p, E, scr, Ip, skip, zr);
-        if constexpr (NPOS > 1) update_row<W, 1, kSweep>(blk, p, E, scr, Ip, skip, zr);
-        update_row<W, 0, kSweep>(blk, p, E, scr, Ip, skip, zr);
+        if constexpr (NPOS > 2) update_row<W, 2, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows);
+        if constexpr (NPOS > 1) update_row<W, 1, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows);
+        update_row<W, 0, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows);
     }
 
     // Chain-wave form: two operand tiles b_J = X_J + W_strict X_J at once (J0, J1 run-time; J1 < 0: one), their MFMA
@@ -809,7 +858,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // `panel(k)` = (pivots of panel k that are not identity padding, +1 / -1: their sign); npan panels.  kSweep: the
     // symmetric sweep of the first npan tile rows (update_row).  Returns 0, or the flag of the pivot block that failed.
     template <int ROLE, bool kSweep, class PanelInfo>
-    static QPX_DEV int factor_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, PanelInfo&& panel)
+    static QPX_DEV int factor_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, int mrows, PanelInfo&& panel)
     {
         constexpr bool kChain = ROLE < 0;
         constexpr int W = kChain ? 0 : ROLE;
@@ -892,7 +941,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                 if (la) pivot_block(blk, p, scr, rd, 16 * (k + 1), panel(k + 1).kmax, panel(k + 1).sign);
             } else {
                 blk.template prio<0>();
-                update_rows<W, kSweep>(blk, p, E, scr, k, la ? k + 1 : -1, zr);
+                update_rows<W, kSweep>(blk, p, E, scr, k, la ? k + 1 : -1, zr, mrows);
                 if (la) publish_rows<W>(p, E, scr, k + 1, false);
                 blk.template prio<3>();
             }
@@ -922,7 +971,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     static QPX_DEV bool ldl_inv_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int m)
     {
         const int npan = (m + 15) / 16 < NBL ? (m + 15) / 16 : NBL;
-        return factor_role<ROLE, false>(blk, p0, E, scr, rd, npan, [m](int k) { return PanelOf{m - 16 * k, 1}; }) == 0;
+        return factor_role<ROLE, false>(blk, p0, E, scr, rd, npan, m, [m](int k) { return PanelOf{m - 16 * k, 1}; }) == 0;
     }
 
     // E: T (SPD, order m, padded with the identity) -> strictly lower: W~ = L~^-1, rd[k] = 1/d_k; false: a pivot

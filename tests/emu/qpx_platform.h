@@ -145,6 +145,27 @@ struct Block {
         }
         wave_sync();
     }
+    // four independent 4x4x4 products (see the HIP header): lane 16 h + 4 blk + j accumulates
+    // sum_k A[lane 16 k + 4 blk + h] * B[lane 16 k + 4 blk + j]
+    void mfma4x4x4(double a, double b, double& c) const
+    {
+        unsigned long long ba, bb;
+        std::memcpy(&ba, &a, 8);
+        std::memcpy(&bb, &b, 8);
+        sh->xchg[tid] = ba;
+        sh->xchg2[tid] = bb;
+        wave_sync();
+        const int base = tid & ~(kWave - 1), h = lane() >> 4, blk = (lane() >> 2) & 3, j = lane() & 3;
+        double acc = c;
+        for (int k = 0; k < 4; ++k) {
+            double av, bv;
+            std::memcpy(&av, &sh->xchg[base + (k << 4) + 4 * blk + h], 8);
+            std::memcpy(&bv, &sh->xchg2[base + (k << 4) + 4 * blk + j], 8);
+            acc = std::fma(av, bv, acc);
+        }
+        c = acc;
+        wave_sync();
+    }
     // f32 form: accumulator register r of lane group g is row 4 g + r
     void mfma16x16x4(float a, float b, float (&c)[4]) const
     {
