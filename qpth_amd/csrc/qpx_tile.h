@@ -640,7 +640,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // update (rows above the panel accumulate the negated inverse of the swept block), the panel's own row becomes
     // (-D^-1 b_Ip)^T b_J instead of b_J.
     template <int W, int PP, bool kSweep>
-    static QPX_DEV void update_row(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr, int mrows)
+    static QPX_DEV void update_row(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr, int mrows, const T (&nrd)[4])
     {
         constexpr int I = rowof(PP, W);
         if constexpr (I >= 0) {
@@ -655,7 +655,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                 // measured 6 % slower, profiles/r03x.)
                 const int nq = mrows - 16 * I >= 16 ? 4 : (mrows - 16 * I <= 0 ? 0 : (mrows - 16 * I + 3) >> 2);
                 if (I > Ip && nq < 4) {
-                    if (nq > 0) update_row_quads<PP, I>(blk, p, E, BT, AT, Ip, skip, zr, nq);
+                    if (nq > 0) update_row_quads<PP, I>(blk, p, E, BT, nrd, Ip, skip, zr, nq);
                     return;
                 }
             }
@@ -667,7 +667,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             } else if (I > Ip || kSweep) {
                 T a[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = AT[I * 256 + r * 64 + p.lane];
+                for (int r = 0; r < 4; ++r) a[r] = kSweep ? AT[I * 256 + r * 64 + p.lane] : nrd[r] * BT[I * 256 + r * 64 + p.lane];
                 // off-diagonal tiles, in groups of at most four (registers), then the diagonal one
                 constexpr int G = NSLOT > 12 ? 2 : 4;          // (interleaved MFMA chains per group: registers)
 #pragma unroll
@@ -712,16 +712,16 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // tile row I (> Ip), row blocks 0 .. nq - 1 of every tile: a[q][s] = the scaled operand tile's entries
     // (4 s + h, 4 q + j) in every block of four lanes of lane row h -- the A operand of the four-block instruction
     template <int PP, int I>
-    static QPX_DEV void update_row_quads(const Block& blk, const Pos& p, Regs& E, const T* BT, const T* AT, int Ip, int skip, T zr, int nq)
+    static QPX_DEV void update_row_quads(const Block& blk, const Pos& p, Regs& E, const T* BT, const T (&nrd)[4], int Ip, int skip, T zr, int nq)
     {
-        const T* ATq = AT + I * 256 + (p.lane & ~15) + (p.lane & 3);
+        const T* ATq = BT + I * 256 + (p.lane & ~15) + (p.lane & 3);      // (scaled by -1/d below: row 4 s + h of the operand tile, h = this lane's row)
         constexpr int G = 4;                         // tiles whose products are interleaved
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q >= nq) break;                      // (uniform)
             T a[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) a[s] = ATq[s * 64 + 4 * q];
+            for (int s = 0; s < 4; ++s) a[s] = nrd[s] * ATq[s * 64 + 4 * q];
 #pragma unroll
             for (int J0 = 0; J0 <= I; J0 += G) {
                 T b[G][4];
@@ -746,16 +746,19 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         }
     }
     template <int W, bool kSweep = false>
-    static QPX_DEV void update_rows(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr, int mrows)
+    static QPX_DEV void update_rows(const Block& blk, const Pos& p, Regs& E, const T* scr, int Ip, int skip, T zr, int mrows, const T (&nrd)[4])
     {
         // heaviest row last: its tiles are the ones the publish that follows does not read
-        if constexpr (NPOS > 2) update_row<W, 2, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows);
-        if constexpr (NPOS > 1) update_row<W, 1, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows);
-        update_row<W, 0, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows);
+        if constexpr (NPOS > 2) update_row<W, 2, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows, nrd);
+        if constexpr (NPOS > 1) update_row<W, 1, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows, nrd);
+        update_row<W, 0, kSweep>(blk, p, E, scr, Ip, skip, zr, mrows, nrd);
     }
 
     // Chain-wave form: two operand tiles b_J = X_J + W_strict X_J at once (J0, J1 run-time; J1 < 0: one), their MFMA
-    // chains interleaved; -> BT and, times -1/d, -> AT
+    // chains interleaved; -> BT and (kScaled: the tile sweep's updates read it), times -1/d, -> AT.  The factorisation's
+    // updates scale their A operands themselves (update_row): sixteen LDS writes less per tile wave in the interval
+    // of a panel that the tile waves bound, four multiplications more in the one the pivot block bounds.
+    template <bool kScaled = true>
     static QPX_DEV void operand_pair(const Block& blk, const Pos& p, T* scr, int J0, int J1, const T (&wa)[4], const T (&nrd)[4])
     {
         const T* X = scr + kX;
@@ -778,13 +781,13 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             BT[J0 * 256 + r * 64 + p.lane] = c0[r];
-            AT[J0 * 256 + r * 64 + p.lane] = nrd[r] * c0[r];
+            if constexpr (kScaled) AT[J0 * 256 + r * 64 + p.lane] = nrd[r] * c0[r];
         }
         if (J1 >= 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 BT[J1 * 256 + r * 64 + p.lane] = c1[r];
-                AT[J1 * 256 + r * 64 + p.lane] = nrd[r] * c1[r];
+                if constexpr (kScaled) AT[J1 * 256 + r * 64 + p.lane] = nrd[r] * c1[r];
             }
         }
     }
@@ -913,7 +916,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                         for (int r = 0; r < 4; ++r) {
                             S[(p.g + 4 * r) * SS + p.c] = sacc[r];
                             BT[(k + 1) * 256 + r * 64 + p.lane] = acc[r];
-                            AT[(k + 1) * 256 + r * 64 + p.lane] = ao[r];
+                            if constexpr (kSweep) AT[(k + 1) * 256 + r * 64 + p.lane] = ao[r];
                         }
                     }
                 } else {
@@ -922,12 +925,12 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                     blk.template prio<0>();
                     constexpr int e0 = W, e1 = W + NWM;
                     const int J0 = (la && e0 > k) ? e0 + 1 : e0, J1 = (la && e1 > k) ? e1 + 1 : e1;
-                    operand_pair(blk, p, scr, J0, J1 < NBL ? J1 : -1, wa, nrd);
+                    operand_pair<kSweep>(blk, p, scr, J0, J1 < NBL ? J1 : -1, wa, nrd);
                     // (entries beyond the first two per wave: NBL > 2 NWM, or the last panel's one extra entry)
 #pragma unroll
                     for (int e2 = W + 2 * NWM; e2 < NBL; e2 += NWM) {
                         const int J2 = (la && e2 > k) ? e2 + 1 : e2;
-                        if (J2 < NBL) operand_pair(blk, p, scr, J2, -1, wa, nrd);
+                        if (J2 < NBL) operand_pair<kSweep>(blk, p, scr, J2, -1, wa, nrd);
                     }
                     blk.template prio<3>();
                 }
@@ -941,7 +944,10 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                 if (la) pivot_block(blk, p, scr, rd, 16 * (k + 1), panel(k + 1).kmax, panel(k + 1).sign);
             } else {
                 blk.template prio<0>();
-                update_rows<W, kSweep>(blk, p, E, scr, k, la ? k + 1 : -1, zr, mrows);
+                T nrd[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nrd[r] = -rd[16 * k + p.g + 4 * r];
+                update_rows<W, kSweep>(blk, p, E, scr, k, la ? k + 1 : -1, zr, mrows, nrd);
                 if (la) publish_rows<W>(p, E, scr, k + 1, false);
                 blk.template prio<3>();
             }
