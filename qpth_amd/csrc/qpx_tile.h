@@ -187,6 +187,12 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         }
     }
     struct Regs { T e[NSLOT][4]; };
+#ifndef QPX_PIVOT_HEAD
+#define QPX_PIVOT_HEAD 2
+#endif
+    // pivots of the next block the chain wave eliminates ahead of barrier Y (same box, C2 loop kernel: 0 -> 0.4749 ms,
+    // 2 -> 0.4709, 4 -> 0.4863, 6 -> 0.5010, 8 -> 0.5128: profiles/r03vb -- the wait it fills is two pivots long)
+    static constexpr int kPivotHead = QPX_PIVOT_HEAD;
     // scratch: X (16 x XS: the 16 old rows of a panel) | S, W (16 x SS: pivot block, its inverse factor) | flag |
     // { part (NWM x NBL x 64) | red (NWM x NROW x 17) } or, during a factorisation, BT (NBL x 256: the operand
     // tiles; chain-wave form: + AT, the same tiles times -1/d) | yrow (MP) | chain-wave form: S2 (256: the diagonal
@@ -403,41 +409,46 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // columns of W are zero).
     // sign: +1 / -1 = the pivots of this block must all be positive / negative (the equality block of the tile sweep);
     // flag[0] = 1 / 2 when one is not.
-    static QPX_DEV void pivot_block(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax, int sign = 1)
+    // (in three steps, so that the chain wave can eliminate the first kPivotHead pivots of the NEXT block in the interval
+    // of a panel in which it otherwise waits for the tile waves' operand tiles -- factor_role)
+    struct PivotState { T a[4]; T dg, myr, vn; };
+    static QPX_DEV void pivot_load(const Block& blk, const Pos& p, const T* scr, PivotState& st)
     {
-        T* S = scr + kS;
+        const T* S = scr + kS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st.a[j] = S[p.c * SS + 4 * p.g + j];
+        st.dg = S[p.c * SS + p.c];
+        st.myr = T(1);
+        st.vn = blk.template grp_bcast<0>(st.a[0]);         // column 0, in every lane group
+    }
+    template <int K0, int K1>
+    static QPX_DEV void pivot_run(const Block& blk, const Pos& p, PivotState& st, int kmax)
+    {
+        static_for<K1 - K0>([&](auto kc) {
+            constexpr int K = K0 + decltype(kc)::value;
+            if (K == 0 || kmax > K) pivot16<K>(blk, p, st.a, st.dg, st.myr, st.vn);
+        });
+    }
+    static QPX_DEV void pivot_store(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax, int sign, const PivotState& st)
+    {
         T* W = scr + kW;
         T* flag = scr + kFlag;
-        T a[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = S[p.c * SS + 4 * p.g + j];
-        T dg = S[p.c * SS + p.c], myr = T(1);
-        T vn = blk.template grp_bcast<0>(a[0]);             // column 0, in every lane group
-        pivot16<0>(blk, p, a, dg, myr, vn);
-        if (kmax > 1) pivot16<1>(blk, p, a, dg, myr, vn);
-        if (kmax > 2) pivot16<2>(blk, p, a, dg, myr, vn);
-        if (kmax > 3) pivot16<3>(blk, p, a, dg, myr, vn);
-        if (kmax > 4) pivot16<4>(blk, p, a, dg, myr, vn);
-        if (kmax > 5) pivot16<5>(blk, p, a, dg, myr, vn);
-        if (kmax > 6) pivot16<6>(blk, p, a, dg, myr, vn);
-        if (kmax > 7) pivot16<7>(blk, p, a, dg, myr, vn);
-        if (kmax > 8) pivot16<8>(blk, p, a, dg, myr, vn);
-        if (kmax > 9) pivot16<9>(blk, p, a, dg, myr, vn);
-        if (kmax > 10) pivot16<10>(blk, p, a, dg, myr, vn);
-        if (kmax > 11) pivot16<11>(blk, p, a, dg, myr, vn);
-        if (kmax > 12) pivot16<12>(blk, p, a, dg, myr, vn);
-        if (kmax > 13) pivot16<13>(blk, p, a, dg, myr, vn);
-        if (kmax > 14) pivot16<14>(blk, p, a, dg, myr, vn);
-        if (kmax > 15) pivot16<15>(blk, p, a, dg, myr, vn);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = (4 * p.g + j < kmax) ? a[j] : T(0);
-        if (p.lane < 16) rd[k0 + p.lane] = myr;
+        for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = (4 * p.g + j < kmax) ? st.a[j] : T(0);
+        if (p.lane < 16) rd[k0 + p.lane] = st.myr;
         // a pivot that is not positive and finite leaves a reciprocal that is not (negative, NaN from inf - inf or
         // 0 * inf further down, 0 or inf); nothing above traps, so one test of the sixteen reciprocals replaces
         // two compares in every pivot's chain
-        const T sr = sign > 0 ? myr : ((p.lane < 16 && p.lane < kmax) ? -myr : myr);     // (skipped pivots keep myr = 1)
+        const T sr = sign > 0 ? st.myr : ((p.lane < 16 && p.lane < kmax) ? -st.myr : st.myr);     // (skipped pivots keep myr = 1)
         const bool bad = blk.any(!(sr > T(0) && sr < T(1e300)));
         if (p.lane == 0) flag[0] = bad ? (sign > 0 ? T(1) : T(2)) : T(0);
+    }
+    static QPX_DEV void pivot_block(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax, int sign = 1)
+    {
+        PivotState st;
+        pivot_load(blk, p, scr, st);
+        pivot_run<0, 16>(blk, p, st, kmax);
+        pivot_store(blk, p, scr, rd, k0, kmax, sign, st);
     }
 
     // The panel's sixteen old rows -> X (and, with_s, the pivot block itself -> S), from the tiles this wave owns.
@@ -882,6 +893,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #ifdef QPX_PANEL_PROF
         cacc[4] = clock64();
 #endif
+        PivotState pst;                       // (chain wave: the next pivot block, carried across the barrier between the intervals)
 #pragma unroll 1
         for (int k = 0; k < npan; ++k) {
             const T zr = flag[0];             // 0 unless a pivot broke down
@@ -918,6 +930,12 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                             BT[(k + 1) * 256 + r * 64 + p.lane] = acc[r];
                             if constexpr (kSweep) AT[(k + 1) * 256 + r * 64 + p.lane] = ao[r];
                         }
+                        // ... and starts on it: the tile waves' operand tiles take longer than this wave's two products,
+                        // the first pivots fill the wait (W, rd and the flag are written after the barrier: the tile
+                        // waves still read this panel's)
+                        blk.wave_sync();
+                        pivot_load(blk, p, scr, pst);
+                        pivot_run<0, kPivotHead>(blk, p, pst, panel(k + 1).kmax);
                     }
                 } else {
                     // the tile waves share the other operand tiles, two each: entries W and W + NWM of the list of the
@@ -941,7 +959,10 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             p = p0.fresh();
             // ---- interval 2: the chain wave eliminates pivot block k+1, the tile waves stream panel k's updates
             if constexpr (kChain) {
-                if (la) pivot_block(blk, p, scr, rd, 16 * (k + 1), panel(k + 1).kmax, panel(k + 1).sign);
+                if (la) {
+                    pivot_run<kPivotHead, 16>(blk, p, pst, panel(k + 1).kmax);
+                    pivot_store(blk, p, scr, rd, 16 * (k + 1), panel(k + 1).kmax, panel(k + 1).sign, pst);
+                }
             } else {
                 blk.template prio<0>();
                 T nrd[4];
