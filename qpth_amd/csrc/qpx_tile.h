@@ -769,8 +769,10 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // chains interleaved; -> BT and (kScaled: the tile sweep's updates read it), times -1/d, -> AT.  The factorisation's
     // updates scale their A operands themselves (update_row): sixteen LDS writes less per tile wave in the interval
     // of a panel that the tile waves bound, four multiplications more in the one the pivot block bounds.
-    template <bool kScaled = true>
-    static QPX_DEV void operand_pair(const Block& blk, const Pos& p, T* scr, int J0, int J1, const T (&wa)[4], const T (&nrd)[4])
+    // kSlices: only the first ns k-slices of four pivots are not padding (the last panel of a matrix whose order is not a
+    // multiple of sixteen: W_pp is the identity there and the panel's old rows are zero)
+    template <bool kScaled = true, bool kSlices = false>
+    static QPX_DEV void operand_pair(const Block& blk, const Pos& p, T* scr, int J0, int J1, const T (&wa)[4], const T (&nrd)[4], int ns = 4)
     {
         const T* X = scr + kX;
         T* BT = scr + kBT;
@@ -785,6 +787,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         QPX_SCHED_FENCE();                      // (the scheduler otherwise runs the two chains one after the other)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (kSlices && s >= ns) break;          // (uniform)
             blk.mfma16x16x4(wa[s], x0[s], c0);
             blk.mfma16x16x4(wa[s], x1[s], c1);
             QPX_SCHED_FENCE();
@@ -943,7 +946,12 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                     blk.template prio<0>();
                     constexpr int e0 = W, e1 = W + NWM;
                     const int J0 = (la && e0 > k) ? e0 + 1 : e0, J1 = (la && e1 > k) ? e1 + 1 : e1;
-                    operand_pair<kSweep>(blk, p, scr, J0, J1 < NBL ? J1 : -1, wa, nrd);
+                    if (la || kSweep) {
+                        operand_pair<kSweep>(blk, p, scr, J0, J1 < NBL ? J1 : -1, wa, nrd);
+                    } else {                     // the last panel: its padded pivots' k-slices contribute nothing
+                        const int km = panel(k).kmax, ns = km >= 16 ? 4 : (km + 3) >> 2;
+                        operand_pair<kSweep, true>(blk, p, scr, J0, J1 < NBL ? J1 : -1, wa, nrd, ns);
+                    }
                     // (entries beyond the first two per wave: NBL > 2 NWM, or the last panel's one extra entry)
 #pragma unroll
                     for (int e2 = W + 2 * NWM; e2 < NBL; e2 += NWM) {
