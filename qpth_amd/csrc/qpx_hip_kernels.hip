@@ -258,7 +258,7 @@ template <int NBL, int NW, bool kBw, bool CH> int launch_kkt_tile(const KktArgs<
     template int launch_kkt_tile<NBL, NW, true, CH>(const KktArgs<double>&, size_t, void*);
 #if !defined(QPX_TILE_ONLY)
 QPX_INSTK(1, 1, false) QPX_INSTK(2, 1, false) QPX_INSTK(4, 1, false) QPX_INSTK(4, 2, false) QPX_INSTK(7, 2, false)
-QPX_INSTK(7, 4, false) QPX_INSTK(7, 4, true)
+QPX_INSTK(7, 4, false) QPX_INSTK(7, 4, true) QPX_INSTK(4, 4, true)
 #endif
 #define QPX_INSTT(NBL, NW, NS, CH) template int launch_ipm_tile<NBL, NW, NS, CH>(const IpmArgs<double>&, size_t, void*);
 #if defined(QPX_TILE_ONLY)
@@ -267,7 +267,7 @@ QPX_INSTT(7, QPX_TILE_ONLY, 2, QPX_TILE_ONLY == 4)
 QPX_INSTT(1, 1, 1, false) QPX_INSTT(1, 1, 2, false) QPX_INSTT(1, 1, 4, false) QPX_INSTT(2, 1, 1, false) QPX_INSTT(2, 1, 2, false)
 QPX_INSTT(2, 1, 4, false) QPX_INSTT(4, 1, 1, false) QPX_INSTT(4, 1, 2, false) QPX_INSTT(4, 1, 4, false) QPX_INSTT(4, 2, 1, false)
 QPX_INSTT(4, 2, 2, false) QPX_INSTT(4, 2, 4, false) QPX_INSTT(7, 2, 2, false) QPX_INSTT(7, 2, 4, false) QPX_INSTT(7, 4, 2, false)
-QPX_INSTT(7, 4, 4, false) QPX_INSTT(7, 4, 2, true) QPX_INSTT(7, 4, 4, true)
+QPX_INSTT(7, 4, 4, false) QPX_INSTT(7, 4, 2, true) QPX_INSTT(7, 4, 4, true) QPX_INSTT(4, 4, 1, true) QPX_INSTT(4, 4, 2, true) QPX_INSTT(4, 4, 4, true)
 #endif
 #endif
 
