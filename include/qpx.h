@@ -102,7 +102,8 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * 1 = always the workgroup kernels; 3 = the large-QP family whenever neq = 0.
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
- * at 1 / 2 / 4; by default the library picks by dtype, size and batch.  Adding 16384 runs the four-wave tile
+ * at 1 / 2 / 4 (four waves at 4 or 7 tile rows = the chain-wave form, which is the default there); by default the
+ * library picks by dtype and size.  Adding 16384 runs the four-wave tile
  * kernels without their chain wave (the round-2 form: every wave owns tile rows and the pivot blocks are not
  * eliminated ahead of the trailing updates) -- kept for same-box A/B.  Adding 32768 runs the pre-factorisation (f64,
  * padded tile rows <= 14) as a symmetric sweep on matrix-core tiles (qpx_tsweep.h) instead of the rank-1 sweep on a
