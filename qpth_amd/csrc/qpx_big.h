@@ -264,8 +264,23 @@ template <class T> struct BigGemmArgs {
     int fuse, fuse_k, fail_bit, tile;
     T* W; size_t sW;
     int no_swizzle;              // A/B: plain (qp, tile) grid instead of the XCD-aware one (launcher only)
+    int transb;                  // Bm is given as [k][column] (the product is A Bm, not A Bm^T): rows bkb0.. of Bm, columns of block brb0 + tj (pipelined form only)
+    int v1;                      // A/B: the round-3 tile kernel (whole 64-deep k-blocks staged, two workgroups per CU)
 };
 QPX_LAYOUT_HD size_t big_gemm_lds_elems() { return (size_t)2 * kBB * kBL; }
+// pipelined form (big_gemm2_body): k-chunks of 16, operands row-major [row][k] with a row stride of kGL elements,
+// two buffers each; a fused launch also needs the staged tile + the diagonal-block scratch (big_diag_block)
+constexpr int kGC = 16;
+template <class T> QPX_LAYOUT_HD constexpr int big_gl() { return sizeof(T) == 8 ? 18 : 20; }
+template <class T> QPX_LAYOUT_HD size_t big_gemm2_lds_elems(bool fused, bool mirror)
+{
+    const size_t pipe = (size_t)4 * kBB * big_gl<T>();
+    const size_t stage = (size_t)kBB * kBL;
+    size_t e = pipe;
+    if (mirror && stage > e) e = stage;
+    if (fused && stage + big_diag_scratch_elems() > e) e = stage + big_diag_scratch_elems();
+    return e;
+}
 
 template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<T>& a, int qp, int tile, T* lds)
 {
@@ -356,6 +371,122 @@ template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<
         int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
         big_diag_block<T>(b, [&](int i, int j) { return As[i * kBL + j]; },
                           a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, As, Bs, a.tile);
+    }
+}
+
+// The same tile product, PIPELINED (round 4; the default).  The round-3 kernel staged whole 64-deep k-blocks (67 KB of
+// LDS: two workgroups per CU) and most of its launches are one to four rounds of workgroups, each a chain of memory
+// latencies (operands -> LDS -> matrix cores -> C).  Here the k-dimension moves in chunks of 16 through two small
+// buffers (37 KB: four workgroups per CU), one barrier per chunk, the next chunk's global loads in flight under the
+// matrix instructions of the current one:
+//   * staging: thread t loads 4 consecutive k of row t / 4 (one or two 128-bit loads; a wave covers 16 rows x 128 B)
+//     and writes them as they are: As[row][k], row stride kGL = 18 doubles (20 floats);
+//   * operands: matrix-instruction step s of a chunk takes k = 4 g + s from lane group g, so a lane's four A (B)
+//     values of a chunk are CONSECUTIVE in LDS: one 128-bit read each for floats, two for doubles, on distinct banks
+//     (36 c + 8 g dwords: sixteen different multiples of four mod 64);
+//   * a mirrored tile goes out through LDS (rows of the transposed tile, coalesced) instead of 8-byte stores at a
+//     stride of one matrix row.
+template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const BigGemmArgs<T>& a, int qp, int tile, T* lds)
+{
+    if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
+    const int ti = tile / a.ntj, tj = tile - ti * a.ntj;
+    const int crb = a.crb0 + ti, ccb = a.ccb0 + tj;
+    if (a.lower && crb < ccb) return;
+    constexpr int LD = big_gl<T>();
+    T* As = lds;                         // [buf][row][LD]
+    T* Bs = lds + 2 * kBB * LD;
+    const T* Ag = a.A + (size_t)qp * a.sA + (size_t)(a.arb0 + ti) * kBB * a.lda + (size_t)a.akb0 * kBB;
+    const T* Bg = a.transb ? a.Bm + (size_t)qp * a.sB + (size_t)a.bkb0 * kBB * a.ldb + (size_t)(a.brb0 + tj) * kBB
+                           : a.Bm + (size_t)qp * a.sB + (size_t)(a.brb0 + tj) * kBB * a.ldb + (size_t)a.bkb0 * kBB;
+    const int lane = b.lane(), w = b.uniform(b.wave()), g = lane >> 4, c16 = lane & 15;
+    const int qr = (w >> 1) * 32, qc = (w & 1) * 32;         // this wave's 32 x 32 quadrant
+    T acc[2][2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[x][y][r] = T(0);
+    T* C = a.C + (size_t)qp * a.sC;
+    const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs : C;
+    const int ldcs = a.Cs ? a.ldcs : a.ldc;
+    T cs[2][2][4];
+    if (!a.zero_init) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = crb * kBB + qr + 16 * x + Block::mfma_row(T(0), g, r), j = ccb * kBB + qc + 16 * y + c16;
+                    cs[x][y][r] = Cs[(size_t)i * ldcs + j];
+                }
+    }
+    // staging coordinates: A (and B as [column][k]): row sr, k 4 sq ..; B as [k][column]: k-row tr, columns 4 tq ..
+    const int sr = b.tid >> 2, sq = b.tid & 3, tr = b.tid >> 4, tq = b.tid & 15;
+    const int nch = a.nk * (kBB / kGC);
+    T pa[4], pb[4];
+    auto fetch = [&](int ch) {
+        ld4(Ag + (size_t)sr * a.lda + ch * kGC + 4 * sq, pa);
+        if (a.transb) ld4(Bg + (size_t)(ch * kGC + tr) * a.ldb + 4 * tq, pb);
+        else ld4(Bg + (size_t)sr * a.ldb + ch * kGC + 4 * sq, pb);
+    };
+    fetch(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        T* Ab = As + (ch & 1) * kBB * LD;
+        T* Bb = Bs + (ch & 1) * kBB * LD;
+        st4(Ab + sr * LD + 4 * sq, pa);
+        if (a.transb) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Bb[(4 * tq + u) * LD + tr] = pb[u];
+        } else {
+            st4(Bb + sr * LD + 4 * sq, pb);
+        }
+        b.sync();        // one barrier per chunk: the buffer written now was last read two chunks ago, before the previous barrier
+        if (ch + 1 < nch) fetch(ch + 1);
+        T a0[4], a1[4], b0[4], b1[4];
+        ld4(Ab + (qr + c16) * LD + 4 * g, a0);
+        ld4(Ab + (qr + 16 + c16) * LD + 4 * g, a1);
+        ld4(Bb + (qc + c16) * LD + 4 * g, b0);
+        ld4(Bb + (qc + 16 + c16) * LD + 4 * g, b1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            b.mfma16x16x4(a0[s], b0[s], acc[0][0]);
+            b.mfma16x16x4(a0[s], b1[s], acc[0][1]);
+            b.mfma16x16x4(a1[s], b0[s], acc[1][0]);
+            b.mfma16x16x4(a1[s], b1[s], acc[1][1]);
+        }
+    }
+    const bool fused = kFuse && a.fuse && tile == 0; // uniform
+    const bool mir = a.mirror && crb != ccb;         // uniform
+    const bool staged = fused || mir;
+    if (staged) b.sync();                            // every wave is done with the operand buffers
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
+                const int i = crb * kBB + il, j = ccb * kBB + jl;
+                T v = a.zero_init ? T(0) : cs[x][y][r];
+                if (a.dg && i == j) v += a.dg[(size_t)qp * a.sdg + i];
+                v = fma_(a.alpha, acc[x][y][r], v);
+                C[(size_t)i * a.ldc + j] = v;
+                if (staged) lds[il * kBL + jl] = v;
+            }
+    if (!staged) return;
+    b.sync();
+    if (mir) {
+        // row r of the transposed tile = column r of the staged one
+        for (int r = w; r < kBB; r += b.nwaves()) C[(size_t)(ccb * kBB + r) * a.ldc + crb * kBB + lane] = lds[lane * kBL + r];
+    }
+    if constexpr (kFuse) {
+        if (fused) {
+            int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
+            big_diag_block<T>(b, [&](int i, int j) { return lds[i * kBL + j]; },
+                              a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, lds, lds + kBB * kBL, a.tile);
+        }
     }
 }
 

@@ -286,11 +286,9 @@ QPX_BIG_KERNEL(k_big_panel, BigPanelArgs, (big_panel_body<T>(b, a, (int)blockIdx
 // re-read the same operand panels, so they should run at the same time on ONE XCD (one L2): with B a multiple of 8
 // the grid is 1-D, XCD x works through the QPs x, x + 8, ... one after the other, tile index fastest.  (The plain
 // (qp, tile) grid puts a QP on one XCD too but runs tile t of sixteen QPs side by side: sixteen panel sets per L2.)
-template <class T> __global__ __launch_bounds__(256) void k_big_gemm(BigGemmArgs<T> a, int ntiles, int swz)
+template <class T> QPX_DEV void big_gemm_where(const BigGemmArgs<T>& a, int ntiles, int swz, int& qp, int& tile)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    int qp = (int)blockIdx.x, tile = (int)blockIdx.y;
+    qp = (int)blockIdx.x; tile = (int)blockIdx.y;
     if (swz) {
         int id = (int)blockIdx.x;
         if (a.fuse) {
@@ -308,7 +306,23 @@ template <class T> __global__ __launch_bounds__(256) void k_big_gemm(BigGemmArgs
             tile = slot % ntiles;
         }
     }
+}
+template <class T> __global__ __launch_bounds__(256) void k_big_gemm(BigGemmArgs<T> a, int ntiles, int swz)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    int qp, tile;
+    big_gemm_where(a, ntiles, swz, qp, tile);
     big_gemm_body<T>(b, a, qp, tile, reinterpret_cast<T*>(qpx_smem));
+}
+// the pipelined form (round 4, default): 37 KB of LDS and <= 128 registers, four workgroups per CU
+template <class T, bool kFuse> __global__ __launch_bounds__(256, (kFuse ? 2 : 4)) void k_big_gemm2(BigGemmArgs<T> a, int ntiles, int swz)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    int qp, tile;
+    big_gemm_where(a, ntiles, swz, qp, tile);
+    big_gemm2_body<T, kFuse>(b, a, qp, tile, reinterpret_cast<T*>(qpx_smem));
 }
 QPX_BIG_KERNEL(k_big_trsv, BigTrsvArgs, (big_trsv_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem))), 256)
 QPX_BIG_KERNEL(k_big_gemv, BigGemvArgs, (big_gemv_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
@@ -341,11 +355,21 @@ template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void* s)
 template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_panel<T>, a, a.B, 1, 256, big_panel_lds_elems() * sizeof(T), s, f); }
 template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* s)
 {
-    static BigLdsFlags f;
-    const size_t lds = big_gemm_lds_elems() * sizeof(T);
+    static BigLdsFlags f, f2;
     const int ntiles = a.nti * a.ntj, swz = (a.B % 8 == 0 && ntiles > 1 && a.fuse && !a.no_swizzle) ? 1 : 0;   // measured (r02i): the trailing updates gain 3 %, R = Zt Zt^T (half its tiles empty) loses 30 %
-    if (allow_big_lds(k_big_gemm<T>, lds, f)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_big_gemm<T>, swz ? dim3(a.B * ntiles) : dim3(a.B, ntiles), dim3(256), lds, (hipStream_t)s, a, ntiles, swz);
+    if (a.v1 && !a.transb) {
+        const size_t lds = big_gemm_lds_elems() * sizeof(T);
+        if (allow_big_lds(k_big_gemm<T>, lds, f)) return QPX_ERR_LAUNCH;
+        hipLaunchKernelGGL(k_big_gemm<T>, swz ? dim3(a.B * ntiles) : dim3(a.B, ntiles), dim3(256), lds, (hipStream_t)s, a, ntiles, swz);
+        return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+    }
+    const size_t lds = big_gemm2_lds_elems<T>(a.fuse != 0, a.mirror != 0) * sizeof(T);
+    if (a.fuse) {
+        if (allow_big_lds(k_big_gemm2<T, true>, lds, f2)) return QPX_ERR_LAUNCH;
+        hipLaunchKernelGGL((k_big_gemm2<T, true>), swz ? dim3(a.B * ntiles) : dim3(a.B, ntiles), dim3(256), lds, (hipStream_t)s, a, ntiles, swz);
+    } else {
+        hipLaunchKernelGGL((k_big_gemm2<T, false>), swz ? dim3(a.B * ntiles) : dim3(a.B, ntiles), dim3(256), lds, (hipStream_t)s, a, ntiles, swz);
+    }
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
 template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_trsv<T>, a, a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f); }

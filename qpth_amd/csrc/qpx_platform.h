@@ -250,6 +250,18 @@ template <> QPX_DEV double GlobalRows<double>::row(int r) const
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, r * kWave * 8, 0));
 }
 
+// four consecutive elements at a 4-element-aligned address: one 128-bit access (float) or two (double)
+template <class T> QPX_DEV void ld4(const T* p, T (&v)[4])
+{
+    const T* q = (const T*)__builtin_assume_aligned(p, 4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T));
+    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+}
+template <class T> QPX_DEV void st4(T* p, const T (&v)[4])
+{
+    T* q = (T*)__builtin_assume_aligned(p, 4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T));
+    q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+}
+
 template <class T> QPX_DEV T fma_(T a, T b, T c);
 template <> QPX_DEV float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <> QPX_DEV double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }

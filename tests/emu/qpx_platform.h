@@ -203,6 +203,9 @@ template <class T> struct GlobalRows {
     T row(int r) const { return base[(size_t)r * kWave + lane]; }
 };
 
+template <class T> inline void ld4(const T* p, T (&v)[4]) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
+template <class T> inline void st4(T* p, const T (&v)[4]) { p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3]; }
+
 template <class T> inline T fma_(T a, T b, T c) { return std::fma(a, b, c); }
 inline float rcp_(float x) { return 1.0f / x; }
 inline double rcp_(double x) { return 1.0 / x; }

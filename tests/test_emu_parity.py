@@ -356,12 +356,14 @@ def test_edge_shapes_match_the_reference(name):
 
 # ---------------------------------------------------------------- round 2: the large-QP family (qpx_big.h)
 @pytest.mark.parametrize("shape,dtype,knob", [((1, 66, 70), torch.float64, 3), ((1, 20, 70), torch.float32, 3),
-                                              ((3, 20, 70), torch.float64, 3 + (3 << 16))])
+                                              ((3, 20, 70), torch.float64, 3 + (3 << 16)),
+                                              ((1, 66, 70), torch.float64, 3 + (1 << 30)), ((1, 20, 70), torch.float32, 3 + (1 << 30))])
 def test_large_qp_family(shape, dtype, knob):
     """BASELINE.json configs[3] runs through a multi-kernel family (blocked Cholesky / triangular solves / MFMA trailing
     updates on 64 x 64 blocks, matrices in HBM).  Forced here (knob 3) at sizes of two and three blocks so that the
     blocked code paths run on the emulator: zhat and every gradient against the oracle.  Third case: the batch
-    split into three parts (knob bits 16..19), as the host does on the GPU to overlap the parts on side streams."""
+    split into three parts (knob bits 16..19), as the host does on the GPU to overlap the parts on side streams.  Knob
+    bit 30: the round-3 GEMM tile kernel instead of the pipelined one (kept for same-box A/B)."""
     B, n, m = shape
     f32 = dtype == torch.float32
     arrs = problems.prof_qp(B, n, m, 0, seed=3, dtype=np.float32 if f32 else np.float64)
