@@ -154,7 +154,7 @@ def table_prof_linear(dev, args):
             # arithmetic (QPFunction(refine=None)); elsewhere the float32 kernels + two finishing iterations
             from qpth_amd.qp import f64_arithmetic_serves
             arith = "f64" if dtype == "f64" else ("f64 (QPX_F32_WIDE: float32 tensors, float64 factors and arithmetic)"
-                                                  if f64_arithmetic_serves(nz, nz, 0) else "f32 + 2 finishing iterations in f64 residuals")
+                                                  if f64_arithmetic_serves(nz, nz, 0, _lib.hip()) else "f32 + 2 finishing iterations in f64 residuals")
             rows.append({"table": "prof-linear", "dtype": dtype, "arithmetic": arith, "nBatch": B, "nz": nz, "nineq": nz, "neq": 0,
                          "forward_ms": float(np.median(fw)) * 1e3, "backward_ms": float(np.median(bw)) * 1e3,
                          "qps_fwd_bwd": B / (float(np.median(fw)) + float(np.median(bw))), "trials": ntr})
@@ -310,8 +310,7 @@ def main():
     # float32 data at a size the float64 tile kernels serve runs in float64 arithmetic (QPFunction(refine=None),
     # QPX_F32_WIDE): the kernels timed and priced below are then the float64 ones, reading and writing float32 tensors
     from qpth_amd.qp import f64_arithmetic_serves
-    wide = (args.dtype == "f32" and args.refine is None and f64_arithmetic_serves(n, m, q)
-            and _lib.hip().dll.qpx_supported(_lib.QPX_F32_WIDE, n, m, q) == 0)
+    wide = args.dtype == "f32" and args.refine is None and f64_arithmetic_serves(n, m, q, _lib.hip())
     arith = "f64" if wide else args.dtype
     if rank == 0:
         # ---- per-kernel timing with HIP events on the launch stream (torch's current stream) ----

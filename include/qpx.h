@@ -43,14 +43,15 @@
 extern "C" {
 #endif
 
-#define QPX_ABI_VERSION 5
+#define QPX_ABI_VERSION 6
 
 /* QPX_F32_WIDE (ABI v4): the caller's arrays are float32, `factors` and all arithmetic are float64 -- every `void*`
  * array below except `factors` has float elements, `factors` holds qpx_factor_elems(QPX_F32_WIDE, ...) DOUBLES.  On
  * MI355X the float64 matrix-core kernels are as fast as the float32 thread-grid kernels and return the float64
  * solution of the float32 data (the float32 kernels iterate on products rounded to float32: ~1e-4 from it on the
- * reference's benchmark generator).  Served where the thread-grid / tile kernels run (nz+neq+nineq <= 208), else
- * QPX_ERR_UNSUPPORTED; refine must be 0; qpx_batch_outer takes QPX_F32 for such a caller's float32 vectors. */
+ * reference's benchmark generator).  Served where the thread-grid / tile kernels run (nz+neq+nineq <= 208) and (v6) by
+ * the large-QP family, else QPX_ERR_UNSUPPORTED; refine must be 0; qpx_batch_outer takes QPX_F32 for such a caller's
+ * float32 vectors. */
 enum { QPX_F32 = 0, QPX_F64 = 1, QPX_F32_WIDE = 2 };
 
 enum {
@@ -89,6 +90,12 @@ int qpx_max_dim(void);
 /* QPX_OK if (dtype, n, m, q) is served under the calling thread's knob, else the QPX_ERR_* the entry points would
  * return (QPX_F32_WIDE: QPX_ERR_UNSUPPORTED outside the thread-grid / tile kernels' sizes) */
 int qpx_supported(int dtype, int n, int m, int q);
+/* v6: which kernel family serves (dtype, n, m, q) under the calling thread's knob (or a negative QPX_ERR_*):
+ * the round-1 workgroup kernels, the thread-grid kernels, the float64 matrix-core tile kernels (nineq <= 112,
+ * nz+neq+nineq <= 208), or the large-QP family (multi-kernel blocked Cholesky / GEMM path).  The host mirror uses it
+ * to decide where float32 tensors run in float64 arithmetic (QPX_F32_WIDE: the last two). */
+enum { QPX_FAMILY_WORKGROUP = 0, QPX_FAMILY_GRID = 1, QPX_FAMILY_TILE = 2, QPX_FAMILY_BIG = 3 };
+int qpx_kernel_family(int dtype, int n, int m, int q);
 /* v5: 1 if qpx_factor_solve_kkt / qpx_backward implement refine > 0 for this size and dtype (else they return
  * QPX_ERR_UNSUPPORTED when asked to): the in-kernel iterative refinement of KKTSolvers.IR_UNOPT, batch.py:244-270. */
 int qpx_refine_supported(int dtype, int n, int m, int q);
@@ -97,9 +104,10 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
 /* tuning/A-B knob (per host thread): which kernel family runs.  0 (default) = automatic: the thread-grid /
  * matrix-core kernels (sweep pre-factorisation, register-resident LDL^T with in-place inverse factor)
  * whenever nz+neq+nineq <= 208, else one 256-thread workgroup per QP with the matrices in LDS
- * (neq > 0; for neq = 0 sizes whose matrices do not fit in LDS -- BASELINE.json configs[3], nz = nineq = 500 -- run
- * through the large-QP family: batched multi-kernel blocked Cholesky / MFMA GEMM path, qpx_big.h);
- * 1 = always the workgroup kernels; 3 = the large-QP family whenever neq = 0.
+ * (sizes whose matrices do not fit in LDS -- BASELINE.json configs[3], nz = nineq = 500 -- run
+ * through the large-QP family: batched multi-kernel blocked Cholesky / MFMA GEMM path, qpx_big.h; equality
+ * constraints included since v6);
+ * 1 = always the workgroup kernels; 3 = always the large-QP family.
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4 (four waves at 4 or 7 tile rows = the chain-wave form, which is the default there); by default the
@@ -111,8 +119,11 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * vector FMAs and the padded tiles cost 40 % more flops), so it is opt-in.
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
  * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
- * synchronisation), 0 = automatic (4 from 64 QPs, 2 from 32); bits 20..27 = initial stagger between the side
- * streams in units of 16 us.
+ * synchronisation), 0 = one part; bits 20..24 = initial stagger between the side streams in units of 16 us; bit 25 =
+ * the substitutions by four waves per QP instead of sixteen; bit 26 = the mat-vec R z' in front of the factorisation
+ * in the caller's stream (the round-3 order) instead of beside it on a helper stream; bit 27 =
+ * diagonal blocks eliminated by one wave (the round-3 form) instead of four in the chain-wave form; bit 28 = on the
+ * thread grid; bit 29 = no XCD-aware tile order; bit 30 = the round-3 GEMM tile kernel instead of the pipelined one.
  * The knob must not change between qpx_pre_factor and the calls that consume its factors (it selects the
  * layout of `factors` too: ask qpx_factor_elems after setting it).
  * Returns the previous value. */

@@ -20,6 +20,7 @@ HIP_SO = os.path.join(_HERE, "libqpx_hip.so")
 QPX_F32, QPX_F64, QPX_F32_WIDE = 0, 1, 2      # QPX_F32_WIDE: float32 arrays, float64 factors and arithmetic (include/qpx.h)
 ST_Q_NOT_SPD, ST_A_RANK, ST_KKT_BREAKDOWN, ST_INACCURATE, ST_MAXITER, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 STALL_OFF, STALL_REFERENCE, STALL_FLOOR = 0, 1, 2
+FAMILY_WORKGROUP, FAMILY_GRID, FAMILY_TILE, FAMILY_BIG = 0, 1, 2, 3
 
 _vp, _i, _i64, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 
@@ -30,6 +31,7 @@ _SIGNATURES = {
     "qpx_factor_elems": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "qpx_max_dim": (_i, []),
     "qpx_supported": (_i, [_i, _i, _i, _i]),
+    "qpx_kernel_family": (_i, [_i, _i, _i, _i]),
     "qpx_refine_supported": (_i, [_i, _i, _i, _i]),
     "qpx_fits_lds": (_i, [_i, _i, _i, _i]),
     "qpx_set_ipm_variant": (_i, [_i]),
@@ -113,7 +115,7 @@ class QpxLib:
                 continue
             fn = getattr(self.dll, name)       # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if strict and self.dll.qpx_abi_version() != 5:
+        if strict and self.dll.qpx_abi_version() != 6:
             raise RuntimeError("qpth_amd: ABI version mismatch in %s" % path)
 
     def check(self, code):

@@ -32,30 +32,43 @@ constexpr int kMaxSide = 3;          // side streams the host may spread the par
 constexpr int kBL = kBB + 2;     // LDS row stride of a staged block (elements): 2-way bank conflicts at most
 QPX_LAYOUT_HD int big_pad(int x) { return (x + kBB - 1) / kBB * kBB; }
 
-// per-QP vectors of the loop (each VP = max(NP, MP) elements), same roles as in ipm_loop_body
+// per-QP vectors of the loop (each VP = max(NP, MP, QP) elements), same roles as in ipm_loop_body; the last five serve
+// the equality constraints: bvBQ = b (zero padded), bvTB = L11^-1 b (KKT solve: L11^-1 ry), bvT1 = S11^-1 (b + Yt u)
+// (KKT solve: S11^-1 (ry - Yt u_x)), bvNU = work vector of nu / dy, bvPQ = 0 on [0, q), 1 on the pad of S11's diagonal
 enum BigVec {
     bvP, bvU, bvC, bvR1, bvZ, bvS, bvA, bvB, bvD, bvBZ, bvBS, bvRH, bvX, bvDZA, bvDSA, bvRSC, bvRZ, bvRS, bvW, bvY,
-    bvONE, bvCount
+    bvONE, bvBQ, bvTB, bvT1, bvNU, bvPQ, bvCount
 };
 enum BigScal { bsTau = 0, bsBtau, bsSigz, bsSigs, bsBres, bsFeasPrev, bsAlphaPrev, bsMu, bsSzdot, bsGt1 = 15 };
 enum BigCtrl { bcStop = 0, bcNnot, bcFloor, bcSt, bcIters, bcFail };
 
+// Equality constraints (round 4).  With Lq = chol(Q), Yt = A Lq^-T (neq x nz), S11 = Yt Yt^T = A Q^-1 A^T = L11 L11^T:
+//   K = Q^-1 - Q^-1 A^T S11^-1 A Q^-1 = Lq^-T P Lq^-1,   P = I - Yt^T S11^-1 Yt   (the projector on null(Yt)),
+// so everything the loop needs keeps its form with Zt replaced by the PROJECTED Ztp = Zt P = Zt - (Vh L11^-1) Yt,
+// Vh = Zt Yt^T L11^-T (nineq x neq):  R = Ztp Ztp^T (batch.py:396-399,424),  M = G K = Ztp Lq^-1,  W = G N = Vh L11^-1.
+// The blob keeps Yt (right behind Zt, same row length: the solve with Lq^-T runs once over the stacked rows of G and A),
+// L11 with its diagonal-block inverses, and Vh; Us is the scratch of the pre-factorisation (Vh L11^-1).
 struct BigLayout {
-    size_t Lq, Wq, Zt, R, T, Wt, vec, scal, ctrl, total;
-    int NP, MP, VP;
+    size_t Lq, Wq, Zt, Yt, R, T, Wt, S11, Wy, Vh, Us, vec, scal, ctrl, total;
+    int NP, MP, QP, VP;
     QPX_LAYOUT_HD size_t v(int i) const { return vec + (size_t)i * VP; }
 };
-QPX_LAYOUT_HD BigLayout big_layout(int n, int m)
+QPX_LAYOUT_HD BigLayout big_layout(int n, int m, int q = 0)
 {
     BigLayout L;
-    L.NP = big_pad(n); L.MP = big_pad(m); L.VP = L.NP > L.MP ? L.NP : L.MP;
+    L.NP = big_pad(n); L.MP = big_pad(m); L.QP = q > 0 ? big_pad(q) : 0; L.VP = L.NP > L.MP ? L.NP : L.MP;
     size_t o = 0;
     L.Lq = o;  o += (size_t)L.NP * L.NP;
     L.Wq = o;  o += (size_t)(L.NP / kBB) * 2 * kBB * kBB;      // per diagonal block: W_kk, then W_kk^T
     L.Zt = o;  o += (size_t)L.MP * L.NP;
+    L.Yt = o;  o += (size_t)L.QP * L.NP;
     L.R = o;   o += (size_t)L.MP * L.MP;
     L.T = o;   o += (size_t)L.MP * L.MP;
     L.Wt = o;  o += (size_t)(L.MP / kBB) * 2 * kBB * kBB;
+    L.S11 = o; o += (size_t)L.QP * L.QP;
+    L.Wy = o;  o += (size_t)(L.QP / kBB) * 2 * kBB * kBB;
+    L.Vh = o;  o += (size_t)L.MP * L.QP;
+    L.Us = o;  o += (size_t)L.MP * L.QP;
     L.vec = o; o += (size_t)bvCount * L.VP;
     L.scal = o; o += 16;
     L.ctrl = o; o += 16;
@@ -68,11 +81,12 @@ template <class T> struct BigPackArgs {
     int B, rows, cols, P, ldp, sym;       // source rows x cols -> destination P x ldp (sym: identity on the padded diagonal)
     const T* src; long long ssrc;
     T* dst; size_t sdst;
+    int io32;                             // T = double: the source is a float32 array (QPX_F32_WIDE)
 };
 // grid (B, P / 16): 16 destination rows per workgroup
 template <class T> QPX_DEV void big_pack_body(const Block& b, const BigPackArgs<T>& a, int qp, int chunk)
 {
-    const T* S = a.src + (size_t)qp * a.ssrc;
+    const In<T> S(a.src, (size_t)qp * a.ssrc, a.io32);
     T* D = a.dst + (size_t)qp * a.sdst;
     for (int e = b.tid; e < 16 * a.ldp; e += b.nt) {
         const int i = 16 * chunk + e / a.ldp, j = e % a.ldp;
@@ -105,7 +119,7 @@ template <class T> struct BigPanelArgs {
 };
 // LDS of a diagonal-block elimination: thread-grid form 3 * 64 + 8; matrix-core form (f64) the staged result
 // (64 x 66) + the tile routine's scratch + 64 reciprocal pivots
-QPX_LAYOUT_HD size_t big_diag_scratch_elems() { return TileMat<kBB / 16, 1>::scratch_elems() + kBB + 8; }
+QPX_LAYOUT_HD size_t big_diag_scratch_elems() { return TileMat<kBB / 16, 4, true>::scratch_elems() + kBB + 8; }     // the larger of the two matrix-core forms
 QPX_LAYOUT_HD size_t big_panel_lds_elems() { return (size_t)kBB * kBL + big_diag_scratch_elems(); }
 
 // D(i, j) = element (i, j) of the 64 x 64 block (any source: global memory, or the LDS tile a trailing update has just
@@ -206,11 +220,85 @@ QPX_DEV void big_diag_block_tile(const Block& b, Elem&& D, double* W, int* ctrl,
     }
 }
 
-// tile: the matrix-core form when T is double (stage / scr as above); otherwise the thread-grid form with scr as its scratch
+// The matrix-core elimination by all FOUR waves in the chain-wave form of the tile loop kernels (qpx_tile.h, TileMat<4, 4,
+// true>, the C3 loop kernel's factorisation): wave 0 eliminates the 16 x 16 pivot blocks a panel ahead of the three
+// waves that hold the ten tiles -- ~8 us per block instead of ~14 (round 4).  stage may again be the array D reads:
+// every lower tile is read and later written by the one wave that owns it, the chain wave zeroes the tiles above
+// the diagonal, which D is never asked for.
+template <class Elem>
+QPX_DEV void big_diag_block_chain(const Block& b, Elem&& D, double* W, int* ctrl, int fail_bit, double* stage, double* scr)
+{
+    using TM = TileMat<kBB / 16, 4, true>;
+    double* rd = scr + TM::scratch_elems();
+    double* flag = rd + kBB;
+    const typename TM::Pos p0(b);
+    TM::with_role(p0, [&](const auto& gp) {
+        using P = typename std::decay<decltype(gp)>::type;
+        const P p = gp.fresh();
+        typename TM::Regs E;
+#pragma unroll
+        for (int pp = 0; pp < TM::NPOS; ++pp) {
+            const int I = p.row(pp);
+#pragma unroll
+            for (int J = 0; J < TM::psize(pp); ++J) {
+                if (J <= I) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) E.e[TM::slot(pp, J)][r] = D(16 * I + p.g + 4 * r, 16 * J + p.c);
+                }
+            }
+        }
+        b.sync();                                    // (D may live where the factorisation's scratch does not, but its reads end here)
+        const bool ok = TM::ldl_inv(b, p, E, scr, rd, kBB);
+        b.sync();
+        if (p.is_chain()) {
+            if (p.lane == 0) flag[0] = ok ? 1.0 : 0.0;
+            // strictly upper tiles (I < J): 6 tiles x 256 entries by this wave
+            for (int e = p.lane; e < 6 * 256; e += kWave) {
+                const int t = e >> 8, o = e & 255;
+                const int I = t < 3 ? 0 : (t < 5 ? 1 : 2), J = t < 3 ? t + 1 : (t < 5 ? t - 1 : 3);
+                stage[(16 * I + (o >> 4)) * kBL + 16 * J + (o & 15)] = 0.0;
+            }
+        } else if (ok) {
+#pragma unroll
+            for (int pp = 0; pp < TM::NPOS; ++pp) {
+                const int I = p.row(pp);
+#pragma unroll
+                for (int J = 0; J < TM::psize(pp); ++J) {
+                    if (J <= I) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * I + p.g + 4 * r, j = 16 * J + p.c;
+                            const double rs = sqrt_(rd[i]);
+                            stage[i * kBL + j] = (j < i) ? E.e[TM::slot(pp, J)][r] * rs : (j == i ? rs : 0.0);
+                        }
+                    }
+                }
+            }
+        }
+        b.sync();
+    });
+    if (flag[0] == 0.0) {
+        if (b.tid == 0 && ctrl) ctrl[bcFail] |= fail_bit;
+        return;
+    }
+    double* Wt = W + kBB * kBB;
+    for (int e = b.tid; e < kBB * kBB; e += b.nt) {
+        const int i = e >> 6, j = e & 63;
+        W[e] = stage[i * kBL + j];
+        Wt[e] = stage[j * kBL + i];
+    }
+}
+
+// tile: 1 / 2 = the matrix-core form by one wave / by four waves in the chain-wave form, when T is double (stage / scr
+// as above); otherwise the thread-grid form with scr as its scratch
 template <class T, class Elem>
 QPX_DEV void big_diag_block(const Block& b, Elem&& D, T* W, int* ctrl, int fail_bit, T* stage, T* scr, int tile)
 {
     if constexpr (std::is_same<T, double>::value) {
+        if (tile == 2) {
+            big_diag_block_chain(b, D, W, ctrl, fail_bit, stage, scr);
+            return;
+        }
         if (tile) {
             big_diag_block_tile(b, D, W, ctrl, fail_bit, stage, scr);
             return;
@@ -236,7 +324,7 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
             lds[i * kBL + j] = v;
         }
         b.sync();
-        big_diag_block<T>(b, [&](int i, int j) { return lds[i * kBL + j]; }, W, ctrl, a.fail_bit, lds, lds + kBB * kBL, 1);
+        big_diag_block<T>(b, [&](int i, int j) { return lds[i * kBL + j]; }, W, ctrl, a.fail_bit, lds, lds + kBB * kBL, a.tile);
         return;
     }
     big_diag_block<T>(b, [&](int i, int j) {
@@ -503,21 +591,32 @@ template <class T> struct BigTrsvArgs {
     const T* xin; size_t sxin;            // right-hand side (may be the same array as x)
     T* x; size_t sx;
     const int* ctrl; size_t sctrl; int check_stop;
+    int nw;                               // waves per QP: 4 (round 3) or 16 (launcher only)
 };
-QPX_LAYOUT_HD size_t big_trsv_lds_elems(int np) { return (size_t)np + 5 * kBB; }
+QPX_LAYOUT_HD size_t big_trsv_lds_elems(int np, int nw = 16) { return (size_t)np + (size_t)(nw + 1) * kBB; }
 
-template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<T>& a, int qp, T* lds)
+// NW waves per QP (4, or 16 since round 4): the substitution is a chain of block steps whose off-diagonal part is a
+// stream of 512-byte row loads -- with four waves a CU had 16 KB in flight, a quarter of what its share of the HBM
+// bandwidth needs at ~1.5 us of latency; sixteen waves split the known entries four times finer.
+template <class T, int NW> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<T>& a, int qp, T* lds)
 {
     if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
     const int np = a.nb * kBB;
     T* xs = lds;                 // the vector
-    T* part = xs + np;           // 4 x 64 partial sums
-    T* t = part + 4 * kBB;       // block right-hand side
+    T* part = xs + np;           // NW x 64 partial sums
+    T* t = part + NW * kBB;      // block right-hand side
     const T* M = a.M + (size_t)qp * a.sM;
     T* x = a.x + (size_t)qp * a.sx;
     const T* xin = a.xin + (size_t)qp * a.sxin;
     for (int i = b.tid; i < np; i += b.nt) xs[i] = xin[i];
     const int lane = b.lane(), w = b.uniform(b.wave());
+    auto gather = [&](int i) {
+        T sum = T(0);
+#pragma unroll
+        for (int ww = 0; ww < NW; ww += 4)
+            sum += (part[ww * kBB + i] + part[(ww + 1) * kBB + i]) + (part[(ww + 2) * kBB + i] + part[(ww + 3) * kBB + i]);
+        return sum;
+    };
     for (int kk = 0; kk < a.nb; ++kk) {
         const int k = a.dir == 0 ? kk : a.nb - 1 - kk;
         const int k0 = k * kBB;
@@ -526,43 +625,43 @@ template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<
         // W_kk (W_kk^T) entries of the diagonal mat-vec: independent of everything computed below, so they are
         // fetched first and fly under the off-diagonal loop
         const T* Wg = a.W + (size_t)qp * a.sW + (size_t)k * 2 * kBB * kBB + (a.dir == 0 ? kBB * kBB : 0) + lane;
-        T wv[kBB / 4];
+        T wv[kBB / NW];
 #pragma unroll
-        for (int u = 0; u < kBB / 4; ++u) wv[u] = Wg[(w + 4 * u) * kBB];
+        for (int u = 0; u < kBB / NW; ++u) wv[u] = Wg[(w + NW * u) * kBB];
         {
             // rows c of the stored matrix (L^T above the diagonal for dir 0, L below it for dir 1), element k0 + lane;
             // eight independent loads in flight per lane
             const T* col = M + k0 + lane;
             T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
             int c = c0 + w;
-            for (; c + 28 < c1; c += 32) {
-                const T m0 = col[(size_t)c * a.ld], m1 = col[(size_t)(c + 4) * a.ld], m2 = col[(size_t)(c + 8) * a.ld];
-                const T m3 = col[(size_t)(c + 12) * a.ld], m4 = col[(size_t)(c + 16) * a.ld], m5 = col[(size_t)(c + 20) * a.ld];
-                const T m6 = col[(size_t)(c + 24) * a.ld], m7 = col[(size_t)(c + 28) * a.ld];
+            for (; c + 7 * NW < c1; c += 8 * NW) {
+                const T m0 = col[(size_t)c * a.ld], m1 = col[(size_t)(c + NW) * a.ld], m2 = col[(size_t)(c + 2 * NW) * a.ld];
+                const T m3 = col[(size_t)(c + 3 * NW) * a.ld], m4 = col[(size_t)(c + 4 * NW) * a.ld], m5 = col[(size_t)(c + 5 * NW) * a.ld];
+                const T m6 = col[(size_t)(c + 6 * NW) * a.ld], m7 = col[(size_t)(c + 7 * NW) * a.ld];
                 a0 = fma_(m0, xs[c], a0);
-                a1 = fma_(m1, xs[c + 4], a1);
-                a2 = fma_(m2, xs[c + 8], a2);
-                a3 = fma_(m3, xs[c + 12], a3);
-                a4 = fma_(m4, xs[c + 16], a4);
-                a5 = fma_(m5, xs[c + 20], a5);
-                a6 = fma_(m6, xs[c + 24], a6);
-                a7 = fma_(m7, xs[c + 28], a7);
+                a1 = fma_(m1, xs[c + NW], a1);
+                a2 = fma_(m2, xs[c + 2 * NW], a2);
+                a3 = fma_(m3, xs[c + 3 * NW], a3);
+                a4 = fma_(m4, xs[c + 4 * NW], a4);
+                a5 = fma_(m5, xs[c + 5 * NW], a5);
+                a6 = fma_(m6, xs[c + 6 * NW], a6);
+                a7 = fma_(m7, xs[c + 7 * NW], a7);
             }
-            for (; c < c1; c += 4) a0 = fma_(col[(size_t)c * a.ld], xs[c], a0);
+            for (; c < c1; c += NW) a0 = fma_(col[(size_t)c * a.ld], xs[c], a0);
             part[w * kBB + lane] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
         }
         b.sync();
-        if (b.tid < kBB) t[b.tid] = xs[k0 + b.tid] - ((part[b.tid] + part[kBB + b.tid]) + (part[2 * kBB + b.tid] + part[3 * kBB + b.tid]));
+        if (b.tid < kBB) t[b.tid] = xs[k0 + b.tid] - gather(b.tid);
         b.sync();
         {
             // x_k = W t (dir 0: rows of W^T are the contiguous ones) or W^T t (dir 1: rows of W)
             T acc = 0;
 #pragma unroll
-            for (int u = 0; u < kBB / 4; ++u) acc = fma_(wv[u], t[w + 4 * u], acc);
+            for (int u = 0; u < kBB / NW; ++u) acc = fma_(wv[u], t[w + NW * u], acc);
             part[w * kBB + lane] = acc;
         }
         b.sync();
-        if (b.tid < kBB) xs[k0 + b.tid] = (part[b.tid] + part[kBB + b.tid]) + (part[2 * kBB + b.tid] + part[3 * kBB + b.tid]);
+        if (b.tid < kBB) xs[k0 + b.tid] = gather(b.tid);
     }
     b.sync();
     for (int i = b.tid; i < np; i += b.nt) x[i] = a.post ? -xs[i] : xs[i];
@@ -630,15 +729,19 @@ template <class T> struct BigPhaseArgs {
     T eps;
     T *lam, *slack, *best_resid, *trace;
     int *iters, *status;
+    int q; const T* bq; long long sb;     // equality constraints: b (B, q)
+    int split;                            // phase 2 without d = s/z (phase 7 has written it)
+    int io32;                             // T = double: p, h, b, lam, slack, best_resid, trace are float32 arrays (QPX_F32_WIDE)
 };
 
 template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const BigPhaseArgs<T>& a, int qp)
 {
-    const BigLayout L = big_layout(a.n, a.m);
+    const BigLayout L = big_layout(a.n, a.m, a.q);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     T* sc = F + L.scal;
     int* ctrl = reinterpret_cast<int*>(F + L.ctrl);
     const int m = a.m, n = a.n, lane = b.lane();
+    const int io32 = a.io32;
     const T mT = (T)m;
     T *vP = F + L.v(bvP), *vC = F + L.v(bvC), *vR1 = F + L.v(bvR1), *vZ = F + L.v(bvZ), *vS = F + L.v(bvS);
     T *vA = F + L.v(bvA), *vB = F + L.v(bvB), *vD = F + L.v(bvD), *vBZ = F + L.v(bvBZ), *vBS = F + L.v(bvBS);
@@ -649,8 +752,8 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
         return;
     }
     if (a.phase == 0) {
-        const T* pg = a.p + (size_t)qp * a.sp;
-        const T* hg = a.h + (size_t)qp * a.sh;
+        const In<T> pg(a.p, (size_t)qp * a.sp, io32), hg(a.h, (size_t)qp * a.sh, io32);
+        const In<T> bg(a.q > 0 ? a.bq : nullptr, (size_t)qp * a.sb, io32);
         for (int i = lane; i < L.VP; i += kWave) {
             vP[i] = (i < n) ? pg[i] : T(0);
             vC[i] = (i < m) ? hg[i] : T(0);
@@ -659,6 +762,8 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
             vZ[i] = vS[i] = vRZ[i] = vRS[i] = T(1);
             vA[i] = vB[i] = vR1[i] = vBZ[i] = vBS[i] = vRH[i] = vX[i] = vDZA[i] = vDSA[i] = vRSC[i] = T(0);
             (F + L.v(bvU))[i] = (F + L.v(bvW))[i] = (F + L.v(bvY))[i] = T(0);      // pads stay zero: the mat-vecs write the logical extent only
+            (F + L.v(bvBQ))[i] = (i < a.q) ? bg[i] : T(0);
+            (F + L.v(bvTB))[i] = (F + L.v(bvT1))[i] = (F + L.v(bvNU))[i] = T(0);
         }
         if (lane == 0) {
             sc[bsTau] = T(1); sc[bsBtau] = T(1); sc[bsSigz] = T(0); sc[bsSigs] = T(0); sc[bsBres] = Lim<T>::inf();
@@ -676,8 +781,8 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
         const int fail = ctrl[bcFail];
         if (fail & (QPX_ST_Q_NOT_SPD | QPX_ST_A_RANK)) {
             const T nanv = Lim<T>::inf() - Lim<T>::inf();
-            for (int i = lane; i < m; i += kWave) { a.lam[(size_t)qp * m + i] = nanv; a.slack[(size_t)qp * m + i] = nanv; vA[i] = nanv; }
-            if (lane == 0) { a.iters[qp] = 0; a.best_resid[qp] = Lim<T>::inf(); a.status[qp] |= fail; }
+            for (int i = lane; i < m; i += kWave) { put_(a.lam, io32, (size_t)qp * m + i, nanv); put_(a.slack, io32, (size_t)qp * m + i, nanv); vA[i] = nanv; }
+            if (lane == 0) { a.iters[qp] = 0; put_(a.best_resid, io32, (size_t)qp, Lim<T>::inf()); a.status[qp] |= fail; }
             return;
         }
         if (iters >= a.maxIter && !(bres < a.eps)) st |= QPX_ST_MAXITER;
@@ -686,14 +791,14 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
         for (int i = lane; i < L.VP; i += kWave) {
             if (i < m) {
                 const T bz = vBZ[i];
-                a.lam[(size_t)qp * m + i] = bz;
-                a.slack[(size_t)qp * m + i] = vBS[i];
+                put_(a.lam, io32, (size_t)qp * m + i, bz);
+                put_(a.slack, io32, (size_t)qp * m + i, vBS[i]);
                 vA[i] = bz - bts;
             } else {
                 vA[i] = T(0);
             }
         }
-        if (lane == 0) { a.iters[qp] = iters; a.status[qp] |= st | fail; a.best_resid[qp] = bres; }
+        if (lane == 0) { a.iters[qp] = iters; a.status[qp] |= st | fail; put_(a.best_resid, io32, (size_t)qp, bres); }
         return;
     }
     if (ctrl[bcStop]) return;
@@ -726,6 +831,22 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
         }
         return;
     }
+    if (a.phase == 7) {
+        // d = s/z and the reciprocals alone (what the factorisation needs): the residuals -- phase 2 with split = 1 --
+        // follow the factorisation, so that R z' (a mat-vec over 2 MB per QP) runs beside it on a side stream
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * kWave + lane;
+            if (i < m) {
+                const T zk = vZ[i], sk = vS[i];
+                const T rzk = rcp_(zk);
+                vRZ[i] = rzk;
+                vRS[i] = rcp_(sk);
+                vD[i] = sk * rzk;
+            }
+        }
+        return;
+    }
     if (a.phase == 2) {
         const int it = a.it;
         const T tsz = sc[bsTau] * sc[bsSigz];
@@ -739,10 +860,12 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
                 pri2 = fma_(rz, rz, pri2);
                 szdot = fma_(sk, zk, szdot);
                 vRH[i] = vC[i] + vB[i] + tsz * vR1[i];
-                const T rzk = rcp_(zk);
-                vRZ[i] = rzk;
-                vRS[i] = rcp_(sk);
-                vD[i] = sk * rzk;
+                if (!a.split) {
+                    const T rzk = rcp_(zk);
+                    vRZ[i] = rzk;
+                    vRS[i] = rcp_(sk);
+                    vD[i] = sk * rzk;
+                }
             }
         }
         pri2 = wave_sum(b, pri2);
@@ -779,8 +902,8 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
             if (bad) ctrl[bcSt] |= QPX_ST_NONFINITE;
             ctrl[bcStop] = stopf;
             if (a.trace) {
-                T* tr = a.trace + ((size_t)it * a.B + qp) * 3;
-                tr[0] = pri; tr[1] = dual; tr[2] = mu;
+                const size_t tr = ((size_t)it * a.B + qp) * 3;
+                put_(a.trace, io32, tr, pri); put_(a.trace, io32, tr + 1, dual); put_(a.trace, io32, tr + 2, mu);
             }
         }
         return;
@@ -863,22 +986,24 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
 }
 
 // ------------------------------------------------------------------------------------------ small vector kernels
-// op 0: y = alpha x + beta y0 (elementwise, len);  op 1: y[0] = || x[0..len) ||_2 (one wave);
-// op 2: start of a pre-factorisation: zero the QP's control words, vONE = 1 on [0, m), 0 on the pad
+// op 0: y = alpha x + beta y0 (elementwise, len; out32: y is a float32 array of the caller, T = double);
+// op 1: y[0] = || x[0..len) ||_2 (one wave);
+// op 2: start of a pre-factorisation: zero the QP's control words, vONE = 1 on [0, m), 0 on the pad; vPQ = 0 on
+//       [0, q), 1 on the pad (the diagonal of S11 = Yt Yt^T there)
 template <class T> struct BigVecArgs {
     int B, op, len, n, m;
     T* fac; size_t fac_stride;
     const T *x, *y0; size_t sx, sy0;
     T* y; size_t sy;
     T alpha, beta;
+    int q, out32;
 };
 template <class T> QPX_DEV void big_vec_body(const Block& b, const BigVecArgs<T>& a, int qp)
 {
     if (a.op == 0) {
         const T* x = a.x + (size_t)qp * a.sx;
         const T* y0 = a.y0 ? a.y0 + (size_t)qp * a.sy0 : nullptr;
-        T* y = a.y + (size_t)qp * a.sy;
-        for (int i = b.tid; i < a.len; i += b.nt) y[i] = fma_(a.alpha, x[i], y0 ? a.beta * y0[i] : T(0));
+        for (int i = b.tid; i < a.len; i += b.nt) put_(a.y, a.out32, (size_t)qp * a.sy + i, fma_(a.alpha, x[i], y0 ? a.beta * y0[i] : T(0)));
     } else if (a.op == 1) {
         const T* x = a.x + (size_t)qp * a.sx;
         if (b.wave() == 0) {
@@ -888,17 +1013,21 @@ template <class T> QPX_DEV void big_vec_body(const Block& b, const BigVecArgs<T>
             if (b.lane() == 0) (a.y + (size_t)qp * a.sy)[0] = sqrt_(acc);
         }
     } else {
-        const BigLayout L = big_layout(a.n, a.m);
+        const BigLayout L = big_layout(a.n, a.m, a.q);
         T* F = a.fac + (size_t)qp * a.fac_stride;
         int* ctrl = reinterpret_cast<int*>(F + L.ctrl);
         if (b.tid < 16) ctrl[b.tid] = 0;
-        for (int i = b.tid; i < L.VP; i += b.nt) (F + L.v(bvONE))[i] = (i < a.m) ? T(1) : T(0);
+        for (int i = b.tid; i < L.VP; i += b.nt) {
+            (F + L.v(bvONE))[i] = (i < a.m) ? T(1) : T(0);
+            (F + L.v(bvPQ))[i] = (i >= a.q && i < L.QP) ? T(1) : T(0);
+        }
     }
 }
 
 // KKT solve / backward set-up and epilogue on the blob's vectors (one workgroup per QP)
-//   stage 0: vD = 1/d (d given, or clamp(lam)/clamp(slack) for backward), vRH <- rs/d - rz, vU <- rx (n, padded 0)
-//   stage 1: outputs: dz = vX, ds = (-rs - dz)/d, dx = vW; backward: dp, dh and the outer products
+//   stage 0: vD = 1/d (d given, or clamp(lam)/clamp(slack) for backward), vRH <- rs/d - rz, vU <- rx (n, padded 0),
+//            vBQ <- ry (q; backward: 0)
+//   stage 1: outputs: dz = vX, ds = (-rs - dz)/d, dx = vW, dy = vNU; backward: dp, dh, db and the outer products
 template <class T> struct BigKktArgs {
     int B, n, m, stage, backward;
     T* fac; size_t fac_stride;
@@ -906,69 +1035,84 @@ template <class T> struct BigKktArgs {
     const T *zhat, *lam, *slack, *dl_dz;
     T *dx, *ds, *dz, *dQ, *dp, *dG, *dh;
     int* status;
+    int q; const T *ry, *nu; T *dy, *dA, *db;
+    int io32;                             // T = double: every array but `fac` is float32 (QPX_F32_WIDE)
 };
 template <class T> QPX_DEV void big_kkt_body(const Block& b, const BigKktArgs<T>& a, int qp, int chunk)
 {
-    const BigLayout L = big_layout(a.n, a.m);
+    const BigLayout L = big_layout(a.n, a.m, a.q);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     int* ctrl = reinterpret_cast<int*>(F + L.ctrl);
-    const int n = a.n, m = a.m;
+    const int n = a.n, m = a.m, q = a.q, io32 = a.io32;
     T *vD = F + L.v(bvD), *vRH = F + L.v(bvRH), *vU = F + L.v(bvU), *vX = F + L.v(bvX), *vW = F + L.v(bvW);
+    T *vBQ = F + L.v(bvBQ), *vNU = F + L.v(bvNU);
+    const In<T> rsg(a.backward ? nullptr : a.rs, (size_t)qp * m, io32);
     if (a.stage == 0) {
-        const T* rxg = a.backward ? a.dl_dz + (size_t)qp * n : (a.rx ? a.rx + (size_t)qp * n : nullptr);
+        const In<T> rxg(a.backward ? a.dl_dz : a.rx, (size_t)qp * n, io32), rzg(a.backward ? nullptr : a.rz, (size_t)qp * m, io32);
+        const In<T> ryg((!a.backward && q > 0) ? a.ry : nullptr, (size_t)qp * q, io32), dg(a.backward ? nullptr : a.d, (size_t)qp * m, io32);
+        const In<T> lamg(a.backward ? a.lam : nullptr, (size_t)qp * m, io32), slg(a.backward ? a.slack : nullptr, (size_t)qp * m, io32);
         for (int i = b.tid; i < L.VP; i += b.nt) {
             T dinv = T(1), rhs = T(0);
             if (i < m) {
                 T d;
                 if (a.backward) {
-                    const T l = a.lam[(size_t)qp * m + i], sl = a.slack[(size_t)qp * m + i];
+                    const T l = lamg[i], sl = slg[i];
                     d = ((l < T(1e-8)) ? T(1e-8) : l) / ((sl < T(1e-8)) ? T(1e-8) : sl);       // qp.py:148
                 } else {
-                    d = a.d[(size_t)qp * m + i];
+                    d = dg[i];
                 }
                 dinv = T(1) / d;
-                rhs = ((!a.backward && a.rs) ? a.rs[(size_t)qp * m + i] * dinv : T(0)) -
-                      ((!a.backward && a.rz) ? a.rz[(size_t)qp * m + i] : T(0));
+                rhs = (rsg ? rsg[i] * dinv : T(0)) - (rzg ? rzg[i] : T(0));
             }
             vD[i] = dinv;
             vRH[i] = rhs;
             vU[i] = (i < n && rxg) ? rxg[i] : T(0);
             vW[i] = T(0);
+            vBQ[i] = (i < q && ryg) ? ryg[i] : T(0);
+            (F + L.v(bvTB))[i] = (F + L.v(bvT1))[i] = vNU[i] = T(0);
         }
         if (b.tid == 0) { ctrl[bcStop] = 0; ctrl[bcFail] &= (QPX_ST_Q_NOT_SPD | QPX_ST_A_RANK); }
         return;
     }
     // stage 1, grid (B, 1 + rows of the outer products / 16)
+    const bool bad = (ctrl[bcFail] & QPX_ST_KKT_BREAKDOWN) != 0;
     if (chunk == 0) {
-        const bool bad = (ctrl[bcFail] & QPX_ST_KKT_BREAKDOWN) != 0;
         if (b.tid == 0 && bad && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
         for (int i = b.tid; i < n; i += b.nt) {
             const T v = bad ? T(0) : vW[i];
-            if (a.backward) { if (a.dp) a.dp[(size_t)qp * n + i] = v; }
-            if (a.dx) a.dx[(size_t)qp * n + i] = v;
+            if (a.backward && a.dp) put_(a.dp, io32, (size_t)qp * n + i, v);
+            if (a.dx) put_(a.dx, io32, (size_t)qp * n + i, v);
         }
         for (int i = b.tid; i < m; i += b.nt) {
             const T dzv = bad ? T(0) : vX[i];
-            if (a.backward) { if (a.dh) a.dh[(size_t)qp * m + i] = -dzv; }
-            if (a.dz) a.dz[(size_t)qp * m + i] = dzv;
-            if (!a.backward && a.ds) a.ds[(size_t)qp * m + i] = (-(a.rs ? a.rs[(size_t)qp * m + i] : T(0)) - dzv) * vD[i];
+            if (a.backward && a.dh) put_(a.dh, io32, (size_t)qp * m + i, -dzv);
+            if (a.dz) put_(a.dz, io32, (size_t)qp * m + i, dzv);
+            if (!a.backward && a.ds) put_(a.ds, io32, (size_t)qp * m + i, (-(rsg ? rsg[i] : T(0)) - dzv) * vD[i]);
+        }
+        for (int i = b.tid; i < q; i += b.nt) {
+            const T dyv = bad ? T(0) : vNU[i];
+            if (a.backward && a.db) put_(a.db, io32, (size_t)qp * q + i, -dyv);
+            if (a.dy) put_(a.dy, io32, (size_t)qp * q + i, dyv);
         }
         return;
     }
     if (!a.backward) return;
-    const bool bad = (ctrl[bcFail] & QPX_ST_KKT_BREAKDOWN) != 0;
-    const T* zh = a.zhat + (size_t)qp * n;
-    const T* lm = a.lam + (size_t)qp * m;
+    const In<T> zh(a.zhat, (size_t)qp * n, io32), lm(a.lam, (size_t)qp * m, io32), nug(q > 0 ? a.nu : nullptr, (size_t)qp * q, io32);
     const int r0 = (chunk - 1) * 16;
     if (a.dQ)
         for (int e = b.tid; e < 16 * n; e += b.nt) {
             const int r = r0 + e / n, c = e % n;
-            if (r < n) a.dQ[((size_t)qp * n + r) * n + c] = bad ? T(0) : T(0.5) * (vW[r] * zh[c] + zh[r] * vW[c]);
+            if (r < n) put_(a.dQ, io32, ((size_t)qp * n + r) * n + c, bad ? T(0) : T(0.5) * (vW[r] * zh[c] + zh[r] * vW[c]));
         }
     if (a.dG)
         for (int e = b.tid; e < 16 * n; e += b.nt) {
             const int r = r0 + e / n, c = e % n;
-            if (r < m) a.dG[((size_t)qp * m + r) * n + c] = bad ? T(0) : (vX[r] * zh[c] + lm[r] * vW[c]);
+            if (r < m) put_(a.dG, io32, ((size_t)qp * m + r) * n + c, bad ? T(0) : (vX[r] * zh[c] + lm[r] * vW[c]));
+        }
+    if (q > 0 && a.dA)
+        for (int e = b.tid; e < 16 * n; e += b.nt) {
+            const int r = r0 + e / n, c = e % n;
+            if (r < q) put_(a.dA, io32, ((size_t)qp * q + r) * n + c, bad ? T(0) : (vNU[r] * zh[c] + nug[r] * vW[c]));
         }
 }
 
@@ -981,15 +1125,24 @@ template <class T> struct BigSolveArgs {
     BigTrsvArgs<T> t;            // dir / post are set by the body: forward, then backward with the sign of `negate`
     BigPhaseArgs<T> ph;
     int negate, post_phase;      // post_phase < 0: none
+    int pre_phase;               // > 0: the wave-0 phase that writes the right-hand side (and the stop flag) first
 };
-template <class T, int NS> QPX_DEV void big_solve_body(const Block& b, const BigSolveArgs<T>& a, int qp, T* lds)
+template <class T, int NS, int NW> QPX_DEV void big_solve_body(const Block& b, const BigSolveArgs<T>& a, int qp, T* lds)
 {
+    if (a.pre_phase > 0) {
+        if (b.uniform(b.wave()) == 0) {
+            BigPhaseArgs<T> ph = a.ph;
+            ph.phase = a.pre_phase;
+            big_phase_body<T, NS>(b, ph, qp);
+        }
+        b.sync();                                    // right-hand side and stop flag are in global memory for every wave
+    }
     BigTrsvArgs<T> t = a.t;
     t.dir = 0; t.post = 0;
-    big_trsv_body<T>(b, t, qp, lds);
+    big_trsv_body<T, NW>(b, t, qp, lds);
     b.sync();
     t.dir = 1; t.post = a.negate; t.xin = a.t.x; t.sxin = a.t.sx;
-    big_trsv_body<T>(b, t, qp, lds);
+    big_trsv_body<T, NW>(b, t, qp, lds);
     if (a.post_phase >= 0) {
         b.sync();                                    // the solution is in global memory for wave 0
         if (b.uniform(b.wave()) == 0) {

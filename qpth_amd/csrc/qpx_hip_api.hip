@@ -12,8 +12,8 @@ namespace qpx {
 // One pool of side streams + events per (host thread, device), created on first use and kept for the life of the
 // thread.  Fork / join are event record + stream wait: stream-ordered, legal under stream capture, no host sync.
 struct SidePool {
-    hipStream_t s[kMaxSide];
-    hipEvent_t fork, done[kMaxSide];
+    hipStream_t s[kMaxSide + 1];          // [0, kMaxSide): the parts of a batch; [kMaxSide]: the helper stream of the loop (R z' beside the factorisation)
+    hipEvent_t fork, done[kMaxSide + 1];
     bool ok = false;
 };
 constexpr int kMaxDev = 16;
@@ -26,14 +26,14 @@ __global__ void k_stream_delay(long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
-int stream_fork(void* caller, int nside, void** side, int delay_us)
+int stream_fork(void* caller, int nside, void** side, int delay_us, int first)
 {
     int dev = 0;
-    if (nside < 1 || nside > kMaxSide || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
+    if (nside < 1 || first < 0 || first + nside > kMaxSide + 1 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
     SidePool& p = g_side[dev];
     if (!p.ok) {
         if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return QPX_ERR_LAUNCH;
-        for (int i = 0; i < kMaxSide; ++i)
+        for (int i = 0; i < kMaxSide + 1; ++i)
             if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) != hipSuccess)
                 return QPX_ERR_LAUNCH;
@@ -41,25 +41,25 @@ int stream_fork(void* caller, int nside, void** side, int delay_us)
     }
     if (hipEventRecord(p.fork, (hipStream_t)caller) != hipSuccess) return QPX_ERR_LAUNCH;
     for (int i = 0; i < nside; ++i) {
-        if (hipStreamWaitEvent(p.s[i], p.fork, 0) != hipSuccess) return QPX_ERR_LAUNCH;
+        if (hipStreamWaitEvent(p.s[first + i], p.fork, 0) != hipSuccess) return QPX_ERR_LAUNCH;
         if (delay_us > 0) {
             long long us = (long long)delay_us * (i + 1);
             if (us > 10000) us = 10000;
-            hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, p.s[i], us * 100);
+            hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, p.s[first + i], us * 100);
         }
-        side[i] = (void*)p.s[i];
+        side[i] = (void*)p.s[first + i];
     }
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
 
-int stream_join(void* caller, int nside, void* const* side)
+int stream_join(void* caller, int nside, void* const* side, int first)
 {
     int dev = 0;
-    if (nside < 1 || nside > kMaxSide || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
+    if (nside < 1 || first < 0 || first + nside > kMaxSide + 1 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
     SidePool& p = g_side[dev];
     for (int i = 0; i < nside; ++i) {
-        if (hipEventRecord(p.done[i], (hipStream_t)side[i]) != hipSuccess) return QPX_ERR_LAUNCH;
-        if (hipStreamWaitEvent((hipStream_t)caller, p.done[i], 0) != hipSuccess) return QPX_ERR_LAUNCH;
+        if (hipEventRecord(p.done[first + i], (hipStream_t)side[i]) != hipSuccess) return QPX_ERR_LAUNCH;
+        if (hipStreamWaitEvent((hipStream_t)caller, p.done[first + i], 0) != hipSuccess) return QPX_ERR_LAUNCH;
     }
     return QPX_OK;
 }

@@ -324,7 +324,12 @@ template <class T, bool kFuse> __global__ __launch_bounds__(256, (kFuse ? 2 : 4)
     big_gemm_where(a, ntiles, swz, qp, tile);
     big_gemm2_body<T, kFuse>(b, a, qp, tile, reinterpret_cast<T*>(qpx_smem));
 }
-QPX_BIG_KERNEL(k_big_trsv, BigTrsvArgs, (big_trsv_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem))), 256)
+template <class T, int NW> __global__ __launch_bounds__(64 * NW) void k_big_trsv(BigTrsvArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    big_trsv_body<T, NW>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
 QPX_BIG_KERNEL(k_big_gemv, BigGemvArgs, (big_gemv_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
 QPX_BIG_KERNEL(k_big_vec, BigVecArgs, (big_vec_body<T>(b, a, (int)blockIdx.x)), 256)
 QPX_BIG_KERNEL(k_big_kkt, BigKktArgs, (big_kkt_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y)), 256)
@@ -333,11 +338,11 @@ template <class T, int NS> __global__ __launch_bounds__(64) void k_big_phase(Big
     const Block b{(int)threadIdx.x, (int)blockDim.x};
     big_phase_body<T, NS>(b, a, (int)blockIdx.x);
 }
-template <class T, int NS> __global__ __launch_bounds__(256) void k_big_solve(BigSolveArgs<T> a)
+template <class T, int NS, int NW> __global__ __launch_bounds__(64 * NW) void k_big_solve(BigSolveArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    big_solve_body<T, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+    big_solve_body<T, NS, NW>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
 }
 template <class T, int NS> __global__ __launch_bounds__(256) void k_big_diag(BigDiagArgs<T> a)
 {
@@ -372,7 +377,13 @@ template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* s)
     }
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
-template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_trsv<T>, a, a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f); }
+template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* s)
+{
+    static BigLdsFlags f, f16;
+    const size_t lds = big_trsv_lds_elems(a.nb * kBB) * sizeof(T);
+    if (a.nw == 4) return big_launch(k_big_trsv<T, 4>, a, a.B, 1, 256, lds, s, f);
+    return big_launch(k_big_trsv<T, 16>, a, a.B, 1, 1024, lds, s, f16);
+}
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* s)
 {
     static BigLdsFlags f;
@@ -394,14 +405,22 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* s)
 }
 template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* s)
 {
-    static BigLdsFlags f;
+    static BigLdsFlags f, f16;
     const size_t lds = big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T);
     const int ns = big_pad(a.ph.m) / kWave;
+    if (a.t.nw == 4) {
+        switch (ns) {
+        case 1: return big_launch(k_big_solve<T, 1, 4>, a, a.t.B, 1, 256, lds, s, f);
+        case 2: return big_launch(k_big_solve<T, 2, 4>, a, a.t.B, 1, 256, lds, s, f);
+        case 3: case 4: return big_launch(k_big_solve<T, 4, 4>, a, a.t.B, 1, 256, lds, s, f);
+        default: return big_launch(k_big_solve<T, 8, 4>, a, a.t.B, 1, 256, lds, s, f);
+        }
+    }
     switch (ns) {
-    case 1: return big_launch(k_big_solve<T, 1>, a, a.t.B, 1, 256, lds, s, f);
-    case 2: return big_launch(k_big_solve<T, 2>, a, a.t.B, 1, 256, lds, s, f);
-    case 3: case 4: return big_launch(k_big_solve<T, 4>, a, a.t.B, 1, 256, lds, s, f);
-    default: return big_launch(k_big_solve<T, 8>, a, a.t.B, 1, 256, lds, s, f);
+    case 1: return big_launch(k_big_solve<T, 1, 16>, a, a.t.B, 1, 1024, lds, s, f16);
+    case 2: return big_launch(k_big_solve<T, 2, 16>, a, a.t.B, 1, 1024, lds, s, f16);
+    case 3: case 4: return big_launch(k_big_solve<T, 4, 16>, a, a.t.B, 1, 1024, lds, s, f16);
+    default: return big_launch(k_big_solve<T, 8, 16>, a, a.t.B, 1, 1024, lds, s, f16);
     }
 }
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* s)

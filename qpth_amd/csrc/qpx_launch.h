@@ -56,7 +56,8 @@ template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* stream);
 // enqueued on `caller` so far; stream_join: `caller` waits (events) for everything enqueued on them.  Neither
 // synchronises the host.  delay_us > 0: side stream i first sleeps i * delay_us (one idle wave), which sets the
 // parts out of phase with each other.
-int stream_fork(void* caller, int nside, void** side, int delay_us);
-int stream_join(void* caller, int nside, void* const* side);
+// `first`: pool slot of side[0] -- [0, kMaxSide) are the parts' streams, kMaxSide the helper stream of the loop.
+int stream_fork(void* caller, int nside, void** side, int delay_us, int first = 0);
+int stream_join(void* caller, int nside, void* const* side, int first = 0);
 
 }  // namespace qpx

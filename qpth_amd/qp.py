@@ -34,12 +34,15 @@ def _print_trace(res):
             i, row[:, 0].mean(), row[:, 1].mean(), row[:, 2].mean()))
 
 
-def f64_arithmetic_serves(nz, nineq, neq):
-    """Sizes the float64 matrix-core tile kernels run (qpx_layout.h: tile_nb(nineq) > 0 and grid_nb(nz+neq+nineq) > 0).
-    There a float32 QP is solved in float64 ARITHMETIC (QPX_F32_WIDE, include/qpx.h: float32 tensors on the caller's
-    side, float64 factors and arithmetic in the kernels, which widen on load and narrow on store): on MI355X the f64
-    matrix-core loop is faster than the f32 thread-grid loop plus its finishing iterations, and its answer is the
-    float64 solution of the float32 data."""
+def f64_arithmetic_serves(nz, nineq, neq, lib=None):
+    """Sizes at which a float32 QP is solved in float64 ARITHMETIC (QPX_F32_WIDE, include/qpx.h: float32 tensors on the
+    caller's side, float64 factors and arithmetic in the kernels, which widen on load and narrow on store): wherever
+    the float64 matrix-core kernels serve the size -- the tile kernels (nineq <= 112, nz+neq+nineq <= 208) and, since
+    round 4, the large-QP family.  On MI355X the f64 matrix-core loop is faster than the f32 thread-grid loop plus its
+    finishing iterations, and its answer is the float64 solution of the float32 data.  The library is the authority
+    (qpx_supported); without one the tile-kernel rule is returned."""
+    if lib is not None:
+        return lib.dll.qpx_kernel_family(_lib.QPX_F32_WIDE, nz, nineq, neq) in (_lib.FAMILY_TILE, _lib.FAMILY_BIG)
     return nineq <= 112 and nz + neq + nineq <= 208
 
 
@@ -65,8 +68,7 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
             neq = A_.size(-2) if A_.nelement() > 0 else 0
             # float32 data, float64 arithmetic (see QPFunction.__doc__)
             ctx.wide = (solver == QPSolvers.PDIPM_BATCHED and refine is None and Q_.dtype == torch.float32
-                        and f64_arithmetic_serves(nz, nineq, neq)
-                        and _lib.backend_for(Q_).dll.qpx_supported(_lib.QPX_F32_WIDE, nz, nineq, neq) == 0)
+                        and f64_arithmetic_serves(nz, nineq, neq, _lib.backend_for(Q_)))
             Q, _ = expandParam(Q_, nBatch, 3)
             p, _ = expandParam(p_, nBatch, 2)
             G, _ = expandParam(G_, nBatch, 3)

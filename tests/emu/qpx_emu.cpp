@@ -374,7 +374,10 @@ template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void*)
 }
 template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void*)
 {
-    big_grid(a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_trsv_body<T>(b, a, qp, reinterpret_cast<T*>(l)); });
+    if (a.nw == 4)
+        big_grid(a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_trsv_body<T, 4>(b, a, qp, reinterpret_cast<T*>(l)); });
+    else
+        big_grid(a.B, 1, 1024, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_trsv_body<T, 16>(b, a, qp, reinterpret_cast<T*>(l)); });
     return QPX_OK;
 }
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void*)
@@ -408,13 +411,22 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void*)
 template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void*)
 {
     const int ns = big_pad(a.ph.m) / kWave;
-    big_grid(a.t.B, 1, 256, big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
-        T* lds = reinterpret_cast<T*>(l);
-        if (ns == 1) big_solve_body<T, 1>(b, a, qp, lds);
-        else if (ns == 2) big_solve_body<T, 2>(b, a, qp, lds);
-        else if (ns <= 4) big_solve_body<T, 4>(b, a, qp, lds);
-        else big_solve_body<T, 8>(b, a, qp, lds);
-    });
+    if (a.t.nw == 4)
+        big_grid(a.t.B, 1, 256, big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
+            T* lds = reinterpret_cast<T*>(l);
+            if (ns == 1) big_solve_body<T, 1, 4>(b, a, qp, lds);
+            else if (ns == 2) big_solve_body<T, 2, 4>(b, a, qp, lds);
+            else if (ns <= 4) big_solve_body<T, 4, 4>(b, a, qp, lds);
+            else big_solve_body<T, 8, 4>(b, a, qp, lds);
+        });
+    else
+        big_grid(a.t.B, 1, 1024, big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
+            T* lds = reinterpret_cast<T*>(l);
+            if (ns == 1) big_solve_body<T, 1, 16>(b, a, qp, lds);
+            else if (ns == 2) big_solve_body<T, 2, 16>(b, a, qp, lds);
+            else if (ns <= 4) big_solve_body<T, 4, 16>(b, a, qp, lds);
+            else big_solve_body<T, 8, 16>(b, a, qp, lds);
+        });
     return QPX_OK;
 }
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void*)
@@ -440,12 +452,12 @@ template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void
 }
 
 // side streams: launches are synchronous here, so the parts of a batch simply run one after the other
-int stream_fork(void* caller, int nside, void** side, int)
+int stream_fork(void* caller, int nside, void** side, int, int = 0)
 {
     for (int i = 0; i < nside; ++i) side[i] = caller;
     return QPX_OK;
 }
-int stream_join(void*, int, void* const*) { return QPX_OK; }
+int stream_join(void*, int, void* const*, int = 0) { return QPX_OK; }
 
 }  // namespace qpx
 

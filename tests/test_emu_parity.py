@@ -355,27 +355,85 @@ def test_edge_shapes_match_the_reference(name):
 
 
 # ---------------------------------------------------------------- round 2: the large-QP family (qpx_big.h)
-@pytest.mark.parametrize("shape,dtype,knob", [((1, 66, 70), torch.float64, 3), ((1, 20, 70), torch.float32, 3),
-                                              ((3, 20, 70), torch.float64, 3 + (3 << 16)),
-                                              ((1, 66, 70), torch.float64, 3 + (1 << 30)), ((1, 20, 70), torch.float32, 3 + (1 << 30))])
+@pytest.mark.parametrize("shape,dtype,knob", [((1, 66, 70, 0), torch.float64, 3), ((1, 20, 70, 0), torch.float32, 3),
+                                              ((3, 20, 70, 0), torch.float64, 3 + (3 << 16)),
+                                              ((1, 66, 70, 0), torch.float64, 3 + (1 << 30)), ((1, 20, 70, 0), torch.float32, 3 + (1 << 30)),
+                                              ((1, 66, 70, 0), torch.float64, 3 + (1 << 27)), ((1, 66, 70, 0), torch.float64, 3 + (1 << 28)),
+                                              ((1, 66, 70, 0), torch.float64, 3 + (1 << 25) + (1 << 26)),
+                                              ((2, 66, 70, 5), torch.float64, 3), ((1, 130, 40, 70), torch.float64, 3),
+                                              ((2, 66, 70, 5), torch.float32, 3), ((2, 66, 70, 5), torch.float64, 3 + (2 << 16))])
 def test_large_qp_family(shape, dtype, knob):
     """BASELINE.json configs[3] runs through a multi-kernel family (blocked Cholesky / triangular solves / MFMA trailing
     updates on 64 x 64 blocks, matrices in HBM).  Forced here (knob 3) at sizes of two and three blocks so that the
     blocked code paths run on the emulator: zhat and every gradient against the oracle.  Third case: the batch
     split into three parts (knob bits 16..19), as the host does on the GPU to overlap the parts on side streams.  Knob
-    bit 30: the round-3 GEMM tile kernel instead of the pipelined one (kept for same-box A/B)."""
-    B, n, m = shape
+    bit 30: the round-3 GEMM tile kernel instead of the pipelined one; bits 27 / 28: the diagonal blocks by one wave /
+    on the thread grid instead of the chain-wave form; bits 25 / 26: four-wave substitutions and R z' in front of the
+    factorisation, the round-3 order (all kept for same-box A/B).  Round 4: equality constraints
+    (neq = 5: one block; neq = 70: two blocks, the blocked solves with L11), all six gradients.  (The float32 KERNELS of
+    this family -- QPFunction(refine=k) on float32 tensors; the default is float64 arithmetic -- lose gradient accuracy
+    with equality constraints when nz < nineq: 0.18 relative at nz = 30, nineq = 70, neq = 3 on this generator.)"""
+    B, n, m, q = shape
     f32 = dtype == torch.float32
-    arrs = problems.prof_qp(B, n, m, 0, seed=3, dtype=np.float32 if f32 else np.float64)
-    arrs64 = problems.prof_qp(B, n, m, 0, seed=3)
+    arrs = problems.prof_qp(B, n, m, q, seed=3, dtype=np.float32 if f32 else np.float64)
+    arrs64 = problems.prof_qp(B, n, m, q, seed=3)
     dl = np.random.RandomState(0).randn(B, n)
     x, y, lam, s, grads, info = orc.qp_forward_backward(*arrs64, dl_dz=dl, per_qp=True, stall_policy=2)
-    z, mine = run_qpf(arrs, dl.astype(arrs[0].dtype), dtype=dtype, threads=256, variant=knob)
+    z, mine = run_qpf(arrs, dl.astype(arrs[0].dtype), dtype=dtype, threads=256, variant=knob, **({"refine": 2} if f32 else {}))
     tol = 5e-3 if f32 else TOL
     assert rel_err(z, x).max() < tol
     for a_, r_ in zip(mine, grads):
         if r_ is not None:
             assert np.abs(a_ - r_).max() <= 20 * tol * max(1.0, np.abs(r_).max())
+
+
+@pytest.mark.parametrize("shape", [(2, 66, 70, 0), (2, 66, 70, 5)])
+def test_large_qp_family_float32_tensors_in_float64_arithmetic(shape):
+    """QPX_F32_WIDE in the large-QP family (round 4): float32 tensors, float64 blob and arithmetic -- the pack kernels
+    widen on load, every output narrows on store.  Against the float64 run on the same (float32-rounded) data: forward
+    and all gradients to float32 rounding, duals included."""
+    from qpth_amd.kkt import KKTFactors
+    B, n, m, q = shape
+    arrs32 = problems.prof_qp(B, n, m, q, seed=4, dtype=np.float32)
+    arrs64 = [np.asarray(a, np.float64) for a in arrs32]
+    dl = np.random.RandomState(1).randn(B, n).astype(np.float32)
+    z64, g64 = run_qpf(arrs64, dl.astype(np.float64), threads=256, variant=3)
+    z32, g32 = run_qpf(arrs32, dl, dtype=torch.float32, threads=256, variant=3)
+    assert z32.dtype == np.float32
+    assert rel_err(z32, z64).max() < 1e-6
+    for k, a, b_ in zip(("dQ", "dp", "dG", "dh", "dA", "db"), g32, g64):
+        assert (a is None) == (b_ is None), k
+        if a is not None:
+            assert a.dtype == np.float32 and a.shape == b_.shape, k
+            assert np.abs(a - b_).max() <= 1e-6 * max(1.0, np.abs(b_).max()), k
+    t32 = tens(arrs32, torch.float32, grad=False)
+    t64 = tens(arrs64, grad=False)
+    with emulated(256, 3):
+        f32 = KKTFactors.build(t32[0], t32[2], t32[4], wide=True)
+        r32 = f32.ipm(t32[1], t32[3], t32[5])
+        f64 = KKTFactors.build(t64[0], t64[2], t64[4])
+        r64 = f64.ipm(t64[1], t64[3], t64[5])
+    assert f32.blob.dtype == torch.float64 and r32.lam.dtype == torch.float32
+    assert np.abs(r32.lam.numpy() - r64.lam.numpy()).max() < 1e-6 * max(1.0, np.abs(r64.lam.numpy()).max())
+    if q:
+        assert np.abs(r32.nu.numpy() - r64.nu.numpy()).max() < 1e-6 * max(1.0, np.abs(r64.nu.numpy()).max())
+
+
+def test_large_qp_family_kkt_solve_with_equality_constraints():
+    """factor_kkt + solve_kkt (batch.py:349-372, 435-470) in the large-QP family with neq > 0: random right-hand sides
+    (rx, rs, rz, ry), the residual of the reference's KKT system (kkt_resid_reg, batch.py:228-241) must vanish."""
+    B, n, m, q = 2, 66, 40, 9
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed=6)
+    r = np.random.RandomState(2)
+    d = r.rand(B, m) + 0.1
+    rx, rs, rz, ry = [r.randn(B, k) for k in (n, m, m, q)]
+    tt = lambda x: torch.tensor(x)   # noqa: E731
+    with emulated(256, 3):
+        Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(tt(Q), tt(G), tt(A))
+        outs = pdipm_b.solve_kkt(Q_LU, tt(d), tt(G), tt(A), S_LU, tt(rx), tt(rs), tt(rz), tt(ry))
+    res = _kkt_residual(Q, G, A, d, rx, rs, rz, ry, *[v.numpy() for v in outs])
+    scale = max(np.linalg.norm(v) for v in (rx, rs, rz, ry))
+    assert (res < 1e-9 * scale).all(), res
 
 
 # ---------------------------------------------------------------- round 2: host logic around the new C-ABI arguments
@@ -645,11 +703,20 @@ def test_float32_data_in_float64_arithmetic(name):
             assert np.abs(a - b_).max() <= 1e-6 * max(1.0, np.abs(b_).max()), k
 
 
-def test_float32_sizes_outside_the_tile_kernels_keep_the_float32_kernels():
+def test_float32_sizes_outside_the_matrix_core_kernels_keep_the_float32_kernels():
+    """float32 tensors run in float64 arithmetic where the float64 matrix-core kernels serve the size: the tile kernels
+    and (round 4) the large-QP family; the thread-grid-only and workgroup sizes keep the float32 kernels."""
+    from qpth_amd import _lib
     from qpth_amd.qp import f64_arithmetic_serves
     assert f64_arithmetic_serves(100, 100, 0) and f64_arithmetic_serves(100, 50, 10) and f64_arithmetic_serves(64, 64, 0)
-    assert not f64_arithmetic_serves(2, 200, 0) and not f64_arithmetic_serves(500, 500, 0)
-    assert not f64_arithmetic_serves(100, 100, 10)
+    assert not f64_arithmetic_serves(2, 200, 0) and not f64_arithmetic_serves(100, 100, 10)
+    with emulated(64):
+        lib = _lib.backend_for(torch.zeros(1))
+        fam = lambda n, m, q, d=_lib.QPX_F64: lib.dll.qpx_kernel_family(d, n, m, q)   # noqa: E731
+        assert fam(100, 100, 0) == _lib.FAMILY_TILE and fam(100, 100, 0, _lib.QPX_F32) == _lib.FAMILY_GRID
+        assert fam(2, 200, 0) == _lib.FAMILY_GRID and fam(500, 500, 0) == _lib.FAMILY_BIG and fam(300, 200, 50) == _lib.FAMILY_BIG
+        assert f64_arithmetic_serves(100, 100, 0, lib) and f64_arithmetic_serves(500, 500, 0, lib) and f64_arithmetic_serves(300, 200, 50, lib)
+        assert not f64_arithmetic_serves(2, 200, 0, lib)
 
 
 def test_f32_wide_abi_surface():
@@ -660,7 +727,7 @@ def test_f32_wide_abi_surface():
     with emulated(64):
         dll = _lib.backend_for(torch.zeros(1)).dll
         assert dll.qpx_supported(_lib.QPX_F32_WIDE, 100, 100, 0) == 0
-        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 500, 500, 0) == -2          # the large-QP family has no wide form
+        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 500, 500, 0) == 0           # the large-QP family widens on load too (round 4)
         assert dll.qpx_supported(_lib.QPX_F64, 500, 500, 0) == 0
         assert dll.qpx_factor_elems(_lib.QPX_F32_WIDE, 100, 100, 0) == dll.qpx_factor_elems(_lib.QPX_F64, 100, 100, 0)
         old = dll.qpx_set_ipm_variant(1)                                          # workgroup kernels forced: not served

@@ -187,7 +187,7 @@ def test_float32_is_as_close_to_f64_as_the_reference_f32(dev):
     z, _ = run_qpf(golden_inputs(g32), g32["dl_dz"], dev, dtype=torch.float32)
     mine = rel_err(z, g64["zhat"]).max()
     ref = rel_err(g32["zhat"], g64["zhat"]).max()
-    assert mine < max(10 * ref, 5e-4), (mine, ref)
+    assert mine < 1e-5, (mine, ref)          # float64 arithmetic on the float32 tensors (QPX_F32_WIDE) at this size: measured 3e-6
 
 
 # ---------------------------------------------------------------- 2. oracle, seeded inputs
@@ -345,6 +345,60 @@ def test_full_size_matches_oracle_c4(dev):
     assert int(res.status.max().item()) & 7 == 0
     assert np.abs(res.lam.cpu().numpy() - lam).max() < 1e-5 * max(1.0, np.abs(lam).max())
     assert np.abs(res.slacks.cpu().numpy() - s).max() < 1e-5 * max(1.0, np.abs(s).max())
+
+
+def test_full_size_c4_float32_tensors(dev):
+    """BASELINE.json configs[3] in float32 at its full size (the quoted C4-f32 rate had no parity test).
+    Since round 4 float32 tensors run the large-QP family in float64 arithmetic (QPX_F32_WIDE: the pack kernels widen on
+    load, outputs narrow on store), so the answer is the float64 solution of the float32 data: every QP within 1e-5
+    of the oracle's float64 answer on the same (float32-rounded) data -- the gate of the C2 / C3 float32 test -- and
+    the p-gradient within 1e-5 of its scale.  The float32 KERNELS (refine=2) are reported beside it as a distribution."""
+    from oracle import qp_oracle as orc
+    B, n, m = 128, 500, 500
+    arrs32 = problems.prof_qp(B, n, m, 0, 0, np.float32)
+    arrs64 = [np.asarray(a, np.float64) for a in arrs32]
+    dl = np.ones((B, n))
+    x, y, lam, s, grads, info = orc.qp_forward_backward(*arrs64, dl_dz=dl)
+    z, mine = run_qpf(arrs32, dl.astype(np.float32), dev, dtype=torch.float32)
+    assert z.dtype == np.float32
+    err = rel_err(z, x)
+    zk, _ = run_qpf(arrs32, dl.astype(np.float32), dev, dtype=torch.float32, refine=2)
+    ek = rel_err(zk, x)
+    print("C4 f32 rel err vs the f64 oracle: default (f64 arithmetic) median %.2e max %.2e | f32 kernels + 2 finishing steps median %.2e max %.2e"
+          % (np.median(err), err.max(), np.median(ek), ek.max()))
+    assert err.max() <= 1e-5, err.max()
+    for k, a_, r_ in zip(("dQ", "dp", "dG", "dh"), mine, grads):
+        assert a_.dtype == np.float32
+        assert np.abs(a_ - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max()), k
+    assert np.median(ek) < 1e-3          # the float32 kernels: a distribution, not a gate (cond(Q) ~ 1e7 at nz = 500)
+
+
+@pytest.mark.parametrize("B,n,m,q,seed", [(16, 300, 200, 50, 11), (8, 150, 400, 70, 12), (4, 500, 500, 100, 13)])
+def test_large_qps_with_equality_constraints(dev, B, n, m, q, seed):
+    """Equality constraints beyond nz+neq+nineq = 208 (VERDICT r3 missing #2: these ran the round-1 workgroup kernels):
+    the large-QP family with the projected Zt (qpx_big.h), zhat, nu, lam, slacks and all six gradients against the
+    oracle.  neq = 50 / 70 / 100: one and two blocks of 64 in the blocked solves with L11."""
+    from oracle import qp_oracle as orc
+    from qpth_amd import _lib
+    from qpth_amd.kkt import KKTFactors
+    assert _lib.hip().dll.qpx_kernel_family(_lib.QPX_F64, n, m, q) == _lib.FAMILY_BIG
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed)
+    dl = np.random.RandomState(seed).randn(B, n)
+    x, y, lam, s, grads, info = orc.qp_forward_backward(Q, p, G, h, A, b, dl_dz=dl)
+    z, mine = run_qpf([Q, p, G, h, A, b], dl, dev)
+    assert rel_err(z, x).max() < TOL
+    for k, a_, r_ in zip(("dQ", "dp", "dG", "dh", "dA", "db"), mine, grads):
+        assert np.abs(a_ - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max()), k
+    tQ, tp, tG, th, tA, tb = to_dev([Q, p, G, h, A, b], dev, grad=False)
+    fac = KKTFactors.build(tQ, tG, tA)
+    res = fac.ipm(tp, th, tb)
+    torch.cuda.synchronize()
+    assert int(res.status.max().item()) & 7 == 0
+    for name, a_, r_ in (("nu", res.nu, y), ("lam", res.lam, lam), ("slacks", res.slacks, s)):
+        assert np.abs(a_.cpu().numpy() - r_).max() < 1e-5 * max(1.0, np.abs(r_).max()), name
+    # the same QPs as float32 tensors (float64 arithmetic): the float64 answer of the rounded data
+    z32, _ = run_qpf([np.asarray(a_, np.float32) for a_ in (Q, p, G, h, A, b)], dl.astype(np.float32), dev, dtype=torch.float32)
+    print("n=%d m=%d q=%d float32 tensors vs the f64 oracle on the f64 data: max rel err %.2e" % (n, m, q, rel_err(z32, x).max()))
 
 
 def test_c5_shard_matches_oracle_and_kkt(dev):
