@@ -184,6 +184,50 @@ def table_prof_gurobi(dev, args):
     return rows
 
 
+def c5_point(rank, world, dev, dtype, barrier, steps=5, warmup=2):
+    """The north star's strong-scaling point on `world` GPUs: BASELINE.json configs[4] (global batch 65 536, nz = nineq = 64,
+    neq = 0), this rank's contiguous slice generated on the device from a per-rank seed (prof-linear.py's generator in
+    torch), fwd+bwd with zhat all_gathered beside the backward, barrier + synchronize on both sides, MAX over ranks."""
+    import torch.distributed as dist
+    GB, n, m = 65536, 64, 64
+    lo, hi = qdist.shard_bounds(GB, rank, world)
+    B = hi - lo
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    L = torch.rand(B, n, n, dtype=dtype, device=dev, generator=gen)
+    Q = L @ L.transpose(1, 2) + 1e-3 * torch.eye(n, dtype=dtype, device=dev)
+    del L
+    G = torch.randn(B, m, n, dtype=dtype, device=dev, generator=gen)
+    z0 = torch.randn(B, n, dtype=dtype, device=dev, generator=gen)
+    h = torch.bmm(G, z0.unsqueeze(2)).squeeze(2) + torch.rand(B, m, dtype=dtype, device=dev, generator=gen)
+    p = torch.randn(B, n, dtype=dtype, device=dev, generator=gen).requires_grad_(True)
+    e = torch.empty(0, dtype=dtype, device=dev)
+    ones = torch.ones(B, n, dtype=dtype, device=dev)
+    qpf = QPFunction(verbose=-1)
+
+    def step():
+        z = qpf(Q, p, G, h, e, e)
+        pending = qdist.gather_batch(z.detach(), GB, async_op=True)
+        z.backward(ones)
+        pending.wait()
+        p.grad = None
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    return {"metric": "QPs/sec (fwd+bwd), C5: GLOBAL batch 65536 nz=64 nineq=64 neq=0 sharded over the GPUs, zhat all_gathered",
+            "value": GB * steps / dt, "unit": "QPs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "scaling": "strong", "global_batch": GB, "per_gpu_batch": B,
+            "data": "synthetic, generated on the device"}
+
+
 # ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -264,9 +308,12 @@ def main():
 
     def step():
         z = qpf(tQ, tp, tG, th, tA, tb)
+        # zhat for the caller's autograd graph: the all_gather runs on RCCL's stream BESIDE the backward launches
+        # (the backward needs nothing from the other ranks) and is waited for at the end of the step
+        pending = qdist.gather_batch(z.detach(), global_B, async_op=True) if gather else None
         z.backward(ones)
-        if gather:
-            qdist.gather_batch(z.detach(), global_B)                       # zhat for the caller's autograd graph
+        if pending is not None:
+            pending.wait()
         if args.shared and distributed:
             qdist.reduce_shared_grad(tQ.grad, B, global_B)
             qdist.reduce_shared_grad(tG.grad, B, global_B)
@@ -306,6 +353,13 @@ def main():
             step()
         barrier()
         chunk_ms.append((time.perf_counter() - c0) / 10 * 1e3)
+
+    # N > 1 on the default configuration: the line ALSO carries the north star's strong-scaling point (BASELINE.json
+    # configs[4]: C5, fixed GLOBAL batch 65 536, nz = nineq = 64, contiguous slices, zhat all_gathered), so that whichever
+    # command the driver runs at N = 1, 2, 4, 8 the record holds both readings of the metric.  Every rank takes part.
+    extra = None
+    if distributed and args.config == "c2" and not args.shared and all(v is None for v in (args.batch, args.nz, args.nineq, args.neq)):
+        extra = {"c5_strong_scaling": c5_point(rank, world, dev, tQ.dtype, barrier)}
 
     # float32 data at a size the float64 tile kernels serve runs in float64 arithmetic (QPFunction(refine=None),
     # QPX_F32_WIDE): the kernels timed and priced below are then the float64 ones, reading and writing float32 tensors
@@ -449,6 +503,8 @@ def main():
                           "backward_all_gradients": t_bwd_all * 1e3, "ipm_all_20_iterations": t_ipm_fixed * 1e3},
             "job_hbm_roofline_frac": value / world * (fwd_r + fwd_w + bwd_r + bwd_w) / HBM_PEAK,
         }
+        if extra is not None:
+            out["extra"] = extra
         print(json.dumps(out))
     if distributed:
         dist.barrier()

@@ -189,6 +189,24 @@ int qpx_backward(int dtype, int B, int n, int m, int q, void* factors, int64_t s
                  int refine, const void* Q, int64_t sQ, const void* G, int64_t sG, const void* A, int64_t sA,
                  int32_t* status, qpx_stream_t stream);
 
+/* v6: the FINISHING STAGE as one kernel -- `steps` iterations of the reference's PDIPM loop in the original variables
+ * (qpth/solvers/pdipm/batch.py:92-198: affine + centring-corrector Newton steps, step lengths batch.py:189-198) started
+ * from the iterate (zhat, nu, lam, slack) the caller passes in, with the KKT residuals (batch.py:93-101) formed from the
+ * caller's Q, p, G, h, A, b in float64 accumulation whatever dtype is, every KKT solve through the factors of
+ * qpx_pre_factor and refined `refine` times on the residual of the original system (kkt_resid_reg / solve_kkt_ir,
+ * batch.py:228-270 -- what forward(solver=KKTSolvers.IR_UNOPT) asks for).  The four arrays are overwritten with the BEST
+ * iterate met (the reference's rule, batch.py:118-139: residual ||rx|| + ||rz|| + ||ry|| + nineq mu, strict <, NaN never
+ * wins; the start iterate competes), best_resid (dtype[B], may be NULL) with its residual.  Served where the
+ * thread-grid / tile kernels run (nz+neq+nineq <= 208; dtype QPX_F32 or QPX_F64): qpx_polish_supported; elsewhere
+ * QPX_ERR_UNSUPPORTED.  Strides as everywhere: elements, 0 = shared by the batch. */
+int qpx_polish_supported(int dtype, int n, int m, int q);
+int qpx_polish(int dtype, int B, int n, int m, int q,
+               const void* Q, int64_t sQ, const void* p, int64_t sp, const void* G, int64_t sG, const void* h, int64_t sh,
+               const void* A, int64_t sA, const void* b, int64_t sb,
+               void* factors, int64_t sfac, int steps, int refine,
+               void* zhat, void* nu, void* lam, void* slack, void* best_resid,
+               int32_t* status, qpx_stream_t stream);
+
 /* Batch-MEAN of the gradient of a parameter that the whole batch shares (qp.py:159-177: the reference
  * forms B outer products and then `.mean(0)`): one contraction over the batch instead,
  *   out (r,c) = scale/B * sum_b ( u[b][r] v[b][c] + w[b][r] x[b][c] )        u, w: (B,r)  v, x: (B,c)

@@ -47,6 +47,9 @@ _SIGNATURES = {
                                   _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "qpx_backward": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "qpx_polish_supported": (_i, [_i, _i, _i, _i]),
+    "qpx_polish": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
+                        _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qpx_batch_outer": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp]),
 }
 ABI_SYMBOLS = tuple(_SIGNATURES)
@@ -172,6 +175,15 @@ class QpxLib:
             _ptr(nu), _ptr(dl_dz), _ptr(dQ), _ptr(dp), _ptr(dG), _ptr(dh), _ptr(dA), _ptr(db),
             _ptr(dx), _ptr(dz), _ptr(dy), int(refine), Qp.ptr, Qp.stride, Gp.ptr, Gp.stride, Ap.ptr, Ap.stride,
             _ptr(status), _stream(factors)))
+
+    # -- batch.py:92-198 in the original variables, as a finishing stage (KKTSolvers.IR_UNOPT, float32 refine=k)
+    def polish(self, B, n, m, q, Q, p, G, h, A, b, factors, sfac, steps, refine, zhat, nu, lam, slack, best_resid, status):
+        Qp, Gp, Ap = Param(Q, 3), Param(G, 3), Param(A, 3)
+        pp, hp, bp = Param(p, 2), Param(h, 2), Param(b, 2)
+        self.check(self.dll.qpx_polish(
+            _dtype_code(factors), B, n, m, q, Qp.ptr, Qp.stride, pp.ptr, pp.stride, Gp.ptr, Gp.stride, hp.ptr, hp.stride,
+            Ap.ptr, Ap.stride, bp.ptr, bp.stride, _ptr(factors), int(sfac), int(steps), int(refine),
+            _ptr(zhat), _ptr(nu), _ptr(lam), _ptr(slack), _ptr(best_resid), _ptr(status), _stream(factors)))
 
     # -- qp.py:159-177, the `.mean(0)` of a shared parameter's gradient as one contraction over the batch
     def batch_outer(self, u, v, w, x, scale, out):

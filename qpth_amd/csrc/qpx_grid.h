@@ -1352,6 +1352,329 @@ QPX_DEV void kkt_grid_body(const Block& b, const KktArgs<T>& a, int qp, T* lds)
     kkt_mat_body<T, GridMat<T, GS, NBL>, kBackward>(b, a, qp, lds);
 }
 
+// ------------------------------------------------------------------------------------------
+// The finishing stage as ONE kernel (round 4; rounds 2-3 ran it as ~30 host-driven tensor ops per step):
+// `steps` iterations of the reference's PDIPM loop (batch.py:92-198: affine + centring-corrector) in the ORIGINAL
+// variables (x, s, z, y), started from the iterate the caller passes in, on the format-3 blob.  The KKT residuals
+//   rx = Q x + p + G^T z + A^T y,   rz = G x + s - h,   ry = A x - b          (batch.py:93-101)
+// are formed from the caller's Q, G, A with double accumulation whatever T is -- the loop kernel iterates on
+// pre-computed products (R = G Q^-1 G^T ...) whose float32 rounding error is a perturbation of the PROBLEM that no
+// number of loop iterations removes; residuals against the original data do.  Per step: one factorisation of
+// T = R + diag(s/z) (ldl_inv, the factor stays in registers), the affine and the corrector solve through the
+// condensed inverse (the `apply` of kkt_mat_role), each refined `refine` times on the residual of the original
+// KKT system (kkt_resid_reg, batch.py:228-241), step lengths, centring -- and the reference's best-iterate rule
+// (batch.py:118-139: strict <, NaN never wins) with the reference's residual ||rx|| + ||rz|| + ||ry|| + nineq mu.
+// out[c] = base[c] + sum_r M1[r][c] v1[r] + sum_r M2[r][c] v2[r] + sum_r M3[r][c] v3[r]   (c < cols; M2 / M3 may be null),
+// ONE double accumulator per output and one rounding to T at the end: the terms of a KKT residual are large and
+// cancel, so a float32 partial sum would bury the residual in its own rounding (thread per column, coalesced rows)
+template <class T, class V>
+QPX_DEV void resid_cols(const Block& blk, T* out, const T* base, int cols, const T* M1, const V* v1, int r1, const T* M2,
+                        const V* v2, int r2, const T* M3, const V* v3, int r3)
+{
+    for (int c = blk.tid; c < cols; c += blk.nt) {
+        double a0 = base ? (double)base[c] : 0.0, a1 = 0, a2 = 0, a3 = 0;
+        auto add = [&](const T* M, const V* v, int rows) {
+            const T* col = M + c;
+            int r = 0;
+            for (; r + 4 <= rows; r += 4) {
+                const T m0 = col[(size_t)r * cols], m1 = col[(size_t)(r + 1) * cols], m2 = col[(size_t)(r + 2) * cols], m3 = col[(size_t)(r + 3) * cols];
+                a0 = fma_((double)m0, (double)v[r], a0);
+                a1 = fma_((double)m1, (double)v[r + 1], a1);
+                a2 = fma_((double)m2, (double)v[r + 2], a2);
+                a3 = fma_((double)m3, (double)v[r + 3], a3);
+            }
+            for (; r < rows; ++r) a0 = fma_((double)col[(size_t)r * cols], (double)v[r], a0);
+        };
+        add(M1, v1, r1);
+        if (M2) add(M2, v2, r2);
+        if (M3) add(M3, v3, r3);
+        out[c] = (T)((a0 + a1) + (a2 + a3));
+    }
+}
+// out[r] = sign * (b1[r] - b2[r] + sum_c M[r][c] v[c])   (r < rows; b1 / b2 may be null): row dots in double, one rounding
+template <class T, class V, class B1>
+QPX_DEV void resid_rows(const Block& blk, T* out, const B1* b1, const T* b2, const T* M, const V* v, int rows, int cols, double sign)
+{
+    constexpr int RB = 4;
+    const int lane = blk.lane(), w = blk.uniform(blk.wave()), nw = blk.nwaves();
+    for (int r0 = w * RB; r0 < rows; r0 += nw * RB) {
+        double acc[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) acc[u] = 0.0;
+        for (int c = lane; c < cols; c += kWave) {
+            const double x = (double)v[c];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = (r0 + u < rows) ? r0 + u : rows - 1;
+                acc[u] = fma_((double)M[(size_t)r * cols + c], x, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) acc[u] = wave_sum(blk, acc[u]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+                if (r0 + u < rows) {
+                    const int r = r0 + u;
+                    out[r] = (T)(sign * ((b1 ? (double)b1[r] : 0.0) - (b2 ? (double)b2[r] : 0.0) + acc[u]));
+                }
+        }
+    }
+}
+
+template <class T, class Mat, class P>
+QPX_DEV void polish_mat_role(const Block& b, const PolishArgs<T>& a, int qp, T* lds, const P& g)
+{
+    constexpr int M8 = Mat::MP, NT = Mat::NT;
+    const int n = a.n, m = a.m, q = a.q;
+    const FacLayout lay = fac_layout(n, m, q, a.images);
+    T* F = a.fac + (size_t)qp * a.fac_stride;
+    const size_t v = align4(max2(max2((size_t)n, (size_t)M8), (size_t)q));
+    T* rd = lds;
+    T* vD = rd + v;       // s/z (1 on the pad): the diagonal added to R
+    T* vZt = vD + v;      // z in T: the affine step's rs
+    T* vRX = vZt + v;     // residuals of the iterate
+    T* vRZ = vRX + v;
+    T* vRY = vRZ + v;
+    T* vRH = vRY + v;     // work vectors of a solve
+    T* vTm = vRH + v;
+    T* vWX = vTm + v;
+    T* vWY = vWX + v;
+    T* vCX = vWY + v;
+    T* vCZ = vCX + v;
+    T* vCY = vCZ + v;
+    T* vDZA = vCY + v;    // affine direction
+    T* vDSA = vDZA + v;
+    T* vDXA = vDSA + v;
+    T* vDYA = vDXA + v;
+    T* vRSC = vDYA + v;   // corrector right-hand side; then ds of the full step
+    T* vDZ = vRSC + v;    // corrector direction, then the full step
+    T* vDX = vDZ + v;
+    T* vDY = vDX + v;
+    T* vZero = vDY + v;
+    T* scT = vZero + v;   // 16 elements of T holding 8 doubles' worth of nothing: keeps the doubles behind it 8-byte aligned
+    // The iterate and the best iterate live in DOUBLE whatever T is: in float32 the rounding of x alone puts a floor of
+    // ~eps32 ||Q|| ||x|| under the residual that ranks the iterates, and the second step could never "win" (measured:
+    // the kernel stayed at 1.1e-4 from the float64 answer where the host version, which iterated in float64, reached 2.6e-5)
+    double* xd = reinterpret_cast<double*>(scT + 16);
+    double* sd = xd + v;
+    double* zd = sd + v;
+    double* yd = zd + v;
+    double* bxd = yd + v;
+    double* bsd = bxd + v;
+    double* bzd = bsd + v;
+    double* byd = bzd + v;
+    double* sc = byd + v; // 16 scalars
+    T* scr = reinterpret_cast<T*>(sc + 16);     // Mat::scratch_elems()
+    enum { kMu = 0, kTot, kBest, kBetter, kAlpha };
+
+    const T* Qg = a.Q + (size_t)qp * a.sQ;
+    const T* Gg = a.G + (size_t)qp * a.sG;
+    const T* Ag = (q > 0) ? a.A + (size_t)qp * a.sA : nullptr;
+    const T* pg = a.p + (size_t)qp * a.sp;
+    const T* hg = a.h + (size_t)qp * a.sh;
+    const T* bg = (q > 0) ? a.b + (size_t)qp * a.sb : nullptr;
+    const int lane = b.lane();
+    const bool w0 = g.lead(b);
+    const double mD = (double)m;
+    const double tiny = (double)Lim<T>::tiny();
+
+    for (int i = b.tid; i < (int)v; i += NT) {
+        xd[i] = (i < n) ? (double)a.zhat[(size_t)qp * n + i] : 0.0;
+        sd[i] = (i < m) ? (double)a.slack[(size_t)qp * m + i] : 1.0;
+        zd[i] = (i < m) ? (double)a.lam[(size_t)qp * m + i] : 1.0;
+        yd[i] = (i < q) ? (double)a.nu[(size_t)qp * q + i] : 0.0;
+        bxd[i] = xd[i]; bsd[i] = sd[i]; bzd[i] = zd[i]; byd[i] = yd[i];
+        vZero[i] = T(0);
+        vDZA[i] = vDSA[i] = vDXA[i] = vDYA[i] = vRSC[i] = vDZ[i] = vDX[i] = vDY[i] = T(0);
+        vRX[i] = vRZ[i] = vRY[i] = vRH[i] = vCX[i] = vCZ[i] = vCY[i] = vWX[i] = vWY[i] = vZt[i] = T(0);
+    }
+    if (b.tid == 0) sc[kBest] = __builtin_huge_val();
+    Mat::sync(b);
+
+    typename Mat::Regs E;
+    bool ok = true;
+    // one application of the condensed KKT inverse with the factor in E (kkt_mat_role::apply)
+    auto apply = [&](const T* rX, const T* rY, T* rH, T* oZ, T* oX, T* oY) {
+        block_matTvec<T, 1>(b, rH, F + lay.MT, rX, n, m);
+        if (q > 0) {
+            Mat::sync(b);
+            for (int j = b.tid; j < m; j += NT) {
+                T acc = rH[j];
+                for (int r = 0; r < q; ++r) acc = fma_(F[lay.W + (size_t)j * q + r], rY[r], acc);
+                rH[j] = acc;
+            }
+        }
+        Mat::sync(b);
+        Mat::solve_neg(b, g, E, rd, m, rH, oZ, vTm, scr);
+        block_matTvec<T, 0>(b, oX, F + lay.Kneg, rX, n, n);
+        Mat::sync(b);
+        block_matvec16<T, 2>(b, oX, F + lay.MT, oZ, n, m);
+        if (q > 0) {
+            Mat::sync(b);
+            block_matTvec<T, 1>(b, oX, F + lay.NTn, rY, q, n);
+            for (int r = b.tid; r < q; r += NT) {
+                T acc = 0;
+                for (int c2 = 0; c2 < q; ++c2) acc = fma_(F[lay.S11i + (size_t)r * q + c2], rY[c2], acc);
+                for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], rX[k], acc);
+                for (int j = 0; j < m; ++j) acc = fma_(-F[lay.W + (size_t)j * q + r], oZ[j], acc);
+                oY[r] = acc;
+            }
+        }
+        Mat::sync(b);
+    };
+    // solve_kkt(rX, rS, rZ, rY) -> (oX, oZ, oY) [ds = (-rS - oZ) s/z is the caller's], refined a.refine times on the
+    // residual of the original system:  resx = Q dx + G^T dz + A^T dy + rx,  resz = G dx + ds + rz,  resy = A dx + ry
+    auto solve = [&](const T* rX, const T* rS, const T* rZ, const T* rY, T* oZ, T* oX, T* oY) {
+        for (int i = b.tid; i < M8; i += NT) vRH[i] = (i < m) ? rS[i] * vD[i] - rZ[i] : T(0);
+        Mat::sync(b);
+        apply(rX, rY, vRH, oZ, oX, oY);
+        for (int it = 0; it < a.refine; ++it) {
+            // resx = rx + Q dx + G^T dz + A^T dy;  -resz = -(ds + rz + G dx);  resy = ry + A dx
+            for (int i = b.tid; i < M8; i += NT) vCZ[i] = (i < m) ? (-rS[i] - oZ[i]) * vD[i] + rZ[i] : T(0);       // ds + rz
+            Mat::sync(b);
+            resid_cols<T, T>(b, vWX, rX, n, Qg, oX, n, Gg, oZ, m, Ag, oY, q);
+            resid_rows<T, T, T>(b, vRH, vCZ, nullptr, Gg, oX, m, n, -1.0);
+            if (Ag) resid_rows<T, T, T>(b, vWY, rY, nullptr, Ag, oX, q, n, 1.0);
+            for (int i = b.tid + m; i < M8; i += NT) vRH[i] = T(0);
+            Mat::sync(b);
+            apply(vWX, vWY, vRH, vCZ, vCX, vCY);
+            for (int i = b.tid; i < n; i += NT) oX[i] += vCX[i];
+            for (int i = b.tid; i < M8; i += NT) oZ[i] += vCZ[i];
+            for (int i = b.tid; i < q; i += NT) oY[i] += vCY[i];
+            Mat::sync(b);
+        }
+    };
+    // min over dv < 0 of -v / dv (inf if none), by the lead wave
+    auto step_len = [&](const double* vv, const T* dv) {
+        double al = __builtin_huge_val();
+        for (int i = lane; i < m; i += kWave) {
+            const double d = (double)dv[i];
+            if (d < 0.0) al = min2_(al, -vv[i] / d);
+        }
+        return wave_min(b, al);
+    };
+
+    for (int st = 0; st <= a.steps; ++st) {
+        // ---- residuals of the current iterate (double accumulation), mu, the reference's total residual, best iterate
+        resid_cols<T, double>(b, vRX, pg, n, Qg, xd, n, Gg, zd, m, Ag, yd, q);         // Q symmetric: column-parallel over its rows
+        resid_rows<T, double, double>(b, vRZ, sd, hg, Gg, xd, m, n, 1.0);
+        if (Ag) resid_rows<T, double, double>(b, vRY, (const double*)nullptr, bg, Ag, xd, q, n, 1.0);
+        Mat::sync(b);
+        if (w0) {
+            double sz = 0, nx = 0, nz = 0, ny = 0;
+            for (int i = lane; i < m; i += kWave) { sz = fma_(sd[i], zd[i], sz); nz = fma_((double)vRZ[i], (double)vRZ[i], nz); }
+            for (int i = lane; i < n; i += kWave) nx = fma_((double)vRX[i], (double)vRX[i], nx);
+            for (int i = lane; i < q; i += kWave) ny = fma_((double)vRY[i], (double)vRY[i], ny);
+            sz = wave_sum(b, sz); nx = wave_sum(b, nx); nz = wave_sum(b, nz); ny = wave_sum(b, ny);
+            const double mu = abs_(sz) / mD;
+            const double tot = sqrt_(nx) + sqrt_(nz) + sqrt_(ny) + mD * mu;
+            const bool better = tot < sc[kBest];                     // false for NaN: a non-finite iterate never wins
+            b.wave_sync();
+            if (lane == 0) {
+                sc[kMu] = mu; sc[kTot] = tot;
+                sc[kBetter] = better ? 1.0 : 0.0;
+                if (better) sc[kBest] = tot;
+            }
+        }
+        Mat::sync(b);
+        if (sc[kBetter] != 0.0 && st > 0) {
+            for (int i = b.tid; i < (int)v; i += NT) { bxd[i] = xd[i]; bsd[i] = sd[i]; bzd[i] = zd[i]; byd[i] = yd[i]; }
+        }
+        if (st == a.steps) break;
+        // ---- factor T = R + diag(s/z)   (d = z/s clamped away from 0 as in the host version: batch.py:146)
+        for (int i = b.tid; i < M8; i += NT) {
+            double d = 1.0;
+            if (i < m) d = max2_(sd[i], tiny) / max2_(zd[i], tiny);
+            vD[i] = (T)d;
+            vZt[i] = (i < m) ? (T)zd[i] : T(0);
+        }
+        Mat::sync(b);
+        Mat::load(b, g, E, Mat::image(F, lay));
+        Mat::add_diag(g, E, vD);
+        ok = Mat::ldl_inv(b, g, E, scr, rd, m);
+        if (!ok) break;                                              // uniform
+        // ---- affine direction: solve_kkt(rx, rs = z, rz, ry)   (batch.py:160-162)
+        solve(vRX, vZt, vRZ, vRY, vDZA, vDXA, vDYA);
+        for (int i = b.tid; i < M8; i += NT) vDSA[i] = (i < m) ? (-vZt[i] - vDZA[i]) * vD[i] : T(0);
+        Mat::sync(b);
+        if (w0) {
+            double al = min2_(step_len(zd, vDZA), step_len(sd, vDSA));
+            al = min2_(al, 1.0);
+            double t3 = 0, sz = 0;
+            for (int i = lane; i < m; i += kWave) {
+                t3 = fma_(sd[i] + al * (double)vDSA[i], zd[i] + al * (double)vDZA[i], t3);
+                sz = fma_(sd[i], zd[i], sz);
+            }
+            t3 = wave_sum(b, t3); sz = wave_sum(b, sz);
+            double sig = t3 / sz;
+            sig = sig * sig * sig;                                   // batch.py:168
+            const double mu = sc[kMu];
+            for (int i = lane; i < m; i += kWave)
+                vRSC[i] = (T)((-mu * sig + (double)vDSA[i] * (double)vDZA[i]) / max2_(sd[i], tiny));       // batch.py:171
+        }
+        Mat::sync(b);
+        // ---- centring-corrector direction: solve_kkt(0, rs_cor, 0, 0)
+        solve(vZero, vRSC, vZero, vZero, vDZ, vDX, vDY);
+        for (int i = b.tid; i < (int)v; i += NT) {
+            const T dsc = (i < m) ? (-vRSC[i] - vDZ[i]) * vD[i] : T(0);
+            vDZ[i] = (i < m) ? vDZA[i] + vDZ[i] : T(0);
+            vRSC[i] = (i < m) ? vDSA[i] + dsc : T(0);                // ds of the full step
+            vDX[i] = (i < n) ? vDXA[i] + vDX[i] : T(0);
+            vDY[i] = (i < q) ? vDYA[i] + vDY[i] : T(0);
+        }
+        Mat::sync(b);
+        if (w0) {
+            double al = 0.999 * min2_(step_len(zd, vDZ), step_len(sd, vRSC));                     // batch.py:193
+            al = min2_(al, 1.0);
+            b.wave_sync();
+            if (lane == 0) sc[kAlpha] = al;
+        }
+        Mat::sync(b);
+        {
+            const double al = sc[kAlpha];
+            for (int i = b.tid; i < (int)v; i += NT) {
+                if (i < n) xd[i] = fma_(al, (double)vDX[i], xd[i]);
+                if (i < m) { sd[i] = fma_(al, (double)vRSC[i], sd[i]); zd[i] = fma_(al, (double)vDZ[i], zd[i]); }
+                if (i < q) yd[i] = fma_(al, (double)vDY[i], yd[i]);
+            }
+        }
+        Mat::sync(b);
+    }
+    if (!ok && b.tid == 0 && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
+    for (int i = b.tid; i < n; i += NT) a.zhat[(size_t)qp * n + i] = (T)bxd[i];
+    for (int i = b.tid; i < m; i += NT) { a.lam[(size_t)qp * m + i] = (T)bzd[i]; a.slack[(size_t)qp * m + i] = (T)bsd[i]; }
+    for (int i = b.tid; i < q; i += NT) a.nu[(size_t)qp * q + i] = (T)byd[i];
+    if (b.tid == 0 && a.best_resid) a.best_resid[qp] = (T)sc[kBest];
+}
+
+template <class T, class Mat>
+QPX_DEV void polish_mat_body(const Block& b, const PolishArgs<T>& a, int qp, T* lds)
+{
+    typename Mat::Pos g(b);
+    g.assign(b, reinterpret_cast<int*>(lds));
+    Mat::with_role(g, [&](const auto& gp) { polish_mat_role<T, Mat>(b, a, qp, lds, gp); });
+}
+
+template <class T, int GS, int NBL>
+QPX_DEV void polish_grid_body(const Block& b, const PolishArgs<T>& a, int qp, T* lds)
+{
+    polish_mat_body<T, GridMat<T, GS, NBL>>(b, a, qp, lds);
+}
+
+// LDS elements (of T, tsize bytes each) of the finishing kernel: 22 vectors + 16 of T, 8 vectors + 16 scalars of double,
+// the matrix operations' scratch
+QPX_LAYOUT_HD size_t lds_elems_polish_mat(size_t mp, size_t scratch, int n, int q, size_t tsize)
+{
+    const size_t v = align4(max2(max2((size_t)n, mp), (size_t)q));
+    return 22 * v + 16 + (8 * v + 16) * (8 / tsize) + scratch;
+}
+QPX_LAYOUT_HD size_t lds_elems_polish_grid(int gs, int nbl, int n, int q, size_t tsize)
+{
+    const size_t mg = (size_t)gs * nbl;
+    return lds_elems_polish_mat(mg, 2 * mg + 4 + (size_t)nbl * gs * gs, n, q, tsize);
+}
+
 // LDS elements of the KKT-solve / backward kernel: 12 vectors + the matrix operations' scratch
 QPX_LAYOUT_HD size_t lds_elems_kkt_mat(size_t mp, size_t scratch, int n, int q)
 {

@@ -8,7 +8,8 @@
 // 3 = kkt/backward, 5 = sweep pre-factorisation (16x16 thread grid),
 // 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only),
 // 10 = batch-mean outer products of shared-parameter gradients, 11 = the large-QP family (qpx_big.h),
-// 12 = sweep pre-factorisation on matrix-core tiles (qpx_tsweep.h, f64 only).
+// 12 = sweep pre-factorisation on matrix-core tiles (qpx_tsweep.h, f64 only), 13 = the finishing stage on matrix-core tiles (f64 only;
+// its thread-grid form lives in 7).
 #include <hip/hip_runtime.h>
 
 #include "../../include/qpx.h"
@@ -28,13 +29,13 @@ template <class K> static int allow_big_lds(K kernel, size_t bytes, BigLdsFlags&
 {
     if (bytes <= 64 * 1024) return QPX_OK;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevFlags) return QPX_ERR_LAUNCH;
-    bool& done = flags.done[dev];
-    if (done) return QPX_OK;
-    done = true;   // idempotent, so a benign race between host threads is harmless
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return QPX_ERR_LAUNCH;
+    const bool tracked = dev < kMaxDevFlags;          // devices beyond the table opt in on every launch (the call is idempotent)
+    if (tracked && flags.done[dev]) return QPX_OK;
     if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kMaxLdsBytes) != hipSuccess)
         return QPX_ERR_LAUNCH;
+    if (tracked) flags.done[dev] = true;   // only after success; idempotent, so a benign race between host threads is harmless
     return QPX_OK;
 }
 
@@ -153,6 +154,23 @@ template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, s
     template int launch_kkt_grid<QPX_TU_REAL, NBL, false>(const KktArgs<QPX_TU_REAL>&, size_t, void*); \
     template int launch_kkt_grid<QPX_TU_REAL, NBL, true>(const KktArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTG(1) QPX_INSTG(2) QPX_INSTG(4) QPX_INSTG(7) QPX_INSTG(10) QPX_INSTG(13)
+// the finishing stage (qpx_polish) on the thread grid
+template <class T, int NBL> __global__ __launch_bounds__(256) void k_polish_grid(PolishArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    polish_grid_body<T, 16, NBL>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T, int NBL> int launch_polish_grid(const PolishArgs<T>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_polish_grid<T, NBL>;
+    static BigLdsFlags big_lds_enabled;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTP(NBL) template int launch_polish_grid<QPX_TU_REAL, NBL>(const PolishArgs<QPX_TU_REAL>&, size_t, void*);
+QPX_INSTP(1) QPX_INSTP(2) QPX_INSTP(4) QPX_INSTP(7) QPX_INSTP(10) QPX_INSTP(13)
 #elif QPX_TU_KERNEL == 8
 template <class T, int NBL, int NS> __global__ __launch_bounds__(64) void k_ipm_grid8(IpmArgs<T> a)
 {
@@ -198,6 +216,24 @@ extern "C" int qpx_sweep_prof_read(unsigned long long* out)      // the chain-fo
 template int launch_tsweep<8>(const PrefactorArgs<double>&, size_t, void*);
 template int launch_tsweep<12>(const PrefactorArgs<double>&, size_t, void*);
 template int launch_tsweep<14>(const PrefactorArgs<double>&, size_t, void*);
+#elif QPX_TU_KERNEL == 13
+// the finishing stage (qpx_polish) on matrix-core tiles, f64: the forms the dispatcher picks by default
+template <int NBL, int NW, bool CH> __global__ __launch_bounds__(64 * NW, 2) void k_polish_tile(PolishArgs<double> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    polish_mat_body<double, TileMat<NBL, NW, CH>>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+}
+template <int NBL, int NW, bool CH> int launch_polish_tile(const PolishArgs<double>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_polish_tile<NBL, NW, CH>;
+    static BigLdsFlags big_lds_enabled;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NW), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+#define QPX_INSTPT(NBL, NW, CH) template int launch_polish_tile<NBL, NW, CH>(const PolishArgs<double>&, size_t, void*);
+QPX_INSTPT(1, 1, false) QPX_INSTPT(2, 1, false) QPX_INSTPT(4, 1, false) QPX_INSTPT(4, 4, true) QPX_INSTPT(7, 4, true)
 #elif QPX_TU_KERNEL == 10 || QPX_TU_KERNEL == 11
 // defined below, outside the launcher chain
 #elif QPX_TU_KERNEL == 9

@@ -37,9 +37,11 @@ namespace qpx {
 template <class T> struct Lim;
 template <> struct Lim<float> {
     static QPX_DEV float inf() { return __builtin_huge_valf(); }
+    static QPX_DEV float tiny() { return 1.17549435e-38f; }
 };
 template <> struct Lim<double> {
     static QPX_DEV double inf() { return __builtin_huge_val(); }
+    static QPX_DEV double tiny() { return 2.2250738585072014e-308; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -346,6 +348,23 @@ template <class T> struct KktArgs {
     const T *Q, *G, *A;
     long long sQ, sG, sA;
     int io32 = 0;                         // T = double only: every array but `fac` is float32 (QPX_F32_WIDE; refine = 0)
+};
+
+// The finishing stage (qpx_polish, include/qpx.h): iterations of the reference's loop in the ORIGINAL variables
+// (batch.py:92-198) on the residuals of the caller's data, started from a given iterate, best iterate kept
+template <class T> struct PolishArgs {
+    int B, n, m, q;
+    T* fac;
+    size_t fac_stride;
+    int images;
+    const T *Q, *G, *A;                   // the caller's problem data (B,n,n) (B,m,n) (B,q,n); stride 0 = shared
+    long long sQ, sG, sA;
+    const T *p, *h, *b;                   // (B,n) (B,m) (B,q)
+    long long sp, sh, sb;
+    T *zhat, *nu, *lam, *slack;           // in: the iterate to start from; out: the best iterate met
+    int steps, refine;
+    T* best_resid;                        // out, may be NULL: the reference's residual of the returned iterate (batch.py:103-107)
+    int* status;
 };
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB of LDS per workgroup

@@ -177,6 +177,13 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             f(RolePos<R>(p));
         }
     }
+    // INVARIANT of the role forms: f is instantiated once per role behind wave-divergent branches, so every role
+    // executes its OWN copy of each s_barrier -- legal on this hardware because s_barrier counts arrivals of the
+    // workgroup's waves whatever their program counters, and correct only as long as EVERY role issues the identical
+    // sequence of workgroup barriers.  A barrier under an `is_chain()` / `row()` test breaks it.  The host-thread
+    // emulator checks exactly this: its barrier is a counting one per workgroup, and a barrier that not every thread
+    // reaches is a reported dead-lock (tests/emu/qpx_emu.cpp: fiber_deadlock), not a hang; the ThreadSanitizer build
+    // runs every role on its own pthreads.
     template <class F> static QPX_DEV void with_role(const Pos& p, F&& f)
     {
         if constexpr (CH) {

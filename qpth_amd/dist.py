@@ -42,16 +42,33 @@ def shard_params(params, nBatch, rank, world, ndims=(3, 2, 3, 2, 3, 2)):
     return out
 
 
-def gather_batch(local, nBatch, group=None):
-    """all_gather row blocks of possibly different length into the full (nBatch, ...) tensor"""
+class _Pending:
+    """An all_gather in flight on the collective's own stream: `.wait()` makes the caller's stream wait for it and returns
+    the full tensor (the caller runs its backward launches in between: the data path has no other collective)."""
+
+    def __init__(self, out, work):
+        self.out, self.work = out, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        return self.out
+
+
+def gather_batch(local, nBatch, group=None, async_op=False):
+    """all_gather row blocks of possibly different length into the full (nBatch, ...) tensor.  async_op (equal slices
+    only): returns a handle whose .wait() yields the tensor -- the collective then overlaps whatever the caller
+    enqueues before waiting (QPFunction's backward needs nothing from the other ranks)."""
     world = dist.get_world_size(group)
     sizes = [shard_bounds(nBatch, r, world) for r in range(world)]
     maxlen = max(hi - lo for lo, hi in sizes)
     if nBatch % world == 0:
         # equal slices (the usual case): one collective straight into the full tensor -- no padding, no concatenation
         out = torch.empty((nBatch,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
+        return _Pending(out, work) if async_op else out
+    if async_op:
+        return _Pending(gather_batch(local, nBatch, group), None)
     pad = torch.zeros((maxlen,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)]

@@ -225,6 +225,30 @@ a non-zero diagonal.
 
     # -- KKTSolvers.IR_UNOPT (batch.py:244-270) as a finishing stage --------------------------------
     def polish(self, p, h, b, res, steps=2, refine=1):
+        """The finishing stage: `steps` iterations of the reference's PDIPM loop (batch.py:92-198) in the original
+        variables, on residuals of the caller's data, from the loop kernel's result; the best iterate is kept.  ONE
+        kernel launch (qpx_polish, include/qpx.h v6) wherever the thread-grid / tile kernels serve the size; the
+        host-driven form below (`_polish_host`) remains for the kernel families without it (large-QP family with
+        explicit float32 `refine=k`, the workgroup kernels behind knob 1).  No host sync either way."""
+        dll = self.lib.dll
+        code = _lib.QPX_F64 if self.dtype == torch.float64 else _lib.QPX_F32
+        if not self.wide and hasattr(dll, "qpx_polish_supported") and dll.qpx_polish_supported(code, self.n, self.m, self.q):
+            B, n, m, q = self.B, self.n, self.m, self.q
+            self._check(p, n, "p")
+            self._check(h, m, "h")
+            if q:
+                self._check(b, q, "b")
+            if not self.refine_ok:
+                refine = 0
+            for name in ("zhat", "lam", "slacks") + (("nu",) if q else ()):
+                setattr(res, name, getattr(res, name).contiguous())
+            with self._knob():
+                self.lib.polish(B, n, m, q, self.Q, p, self.G, h, self.A if q else None, b if q else None, self.blob, self.sfac,
+                                steps, refine, res.zhat, res.nu if q else None, res.lam, res.slacks, None, self.status)
+            return res
+        return self._polish_host(p, h, b, res, steps, refine)
+
+    def _polish_host(self, p, h, b, res, steps=2, refine=1):
         """`steps` iterations of the reference's PDIPM loop (batch.py:92-198: affine + centring-corrector) in the ORIGINAL
         variables (x, s, z, y), started from the loop kernel's result, with the KKT residuals evaluated from the
         caller's Q, G, A in float64 and every solve refined in the kernel (solve_kkt(..., refine)) where the kernel family
@@ -335,15 +359,16 @@ a non-zero diagonal.
             self.lib.backward(B, n, m, q, self.blob, self.sfac, zh, lm, self._vec(slacks, m, "slacks"), nv,
                               self._vec(dl_dz, n, "dl_dz"), dQ, dp, dG, dh, dA, db, self.status, dx, dz, dy,
                               refine=refine, Q=self.Q, G=self.G, A=self.A, wide=self.wide)
-        if wQ and sQ:
-            dQ = torch.empty(n, n, dtype=dt, device=dev)
-            self.lib.batch_outer(dx, zh, zh, dx, 0.5, dQ)
-        if wG and sG:
-            dG = torch.empty(m, n, dtype=dt, device=dev)
-            self.lib.batch_outer(dz, zh, lm, dx, 1.0, dG)
-        if wA and sA:
-            dA = torch.empty(q, n, dtype=dt, device=dev)
-            self.lib.batch_outer(dy, zh, nv, dx, 1.0, dA)
+        with self._knob():           # (their launches too need the factors' device current)
+            if wQ and sQ:
+                dQ = torch.empty(n, n, dtype=dt, device=dev)
+                self.lib.batch_outer(dx, zh, zh, dx, 0.5, dQ)
+            if wG and sG:
+                dG = torch.empty(m, n, dtype=dt, device=dev)
+                self.lib.batch_outer(dz, zh, lm, dx, 1.0, dG)
+            if wA and sA:
+                dA = torch.empty(q, n, dtype=dt, device=dev)
+                self.lib.batch_outer(dy, zh, nv, dx, 1.0, dA)
         if wp and sp:
             dp = dx.mean(0)
         if wh and sh:

@@ -344,6 +344,25 @@ template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, s
     return QPX_OK;
 }
 
+template <class T, int NBL> int launch_polish_grid(const PolishArgs<T>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
+        T* base = reinterpret_cast<T*>(lds.data());
+        run_block(256, [&](const Block& b) { polish_grid_body<T, 16, NBL>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
+template <int NBL, int NW, bool CH> int launch_polish_tile(const PolishArgs<double>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
+        double* base = reinterpret_cast<double*>(lds.data());
+        run_block(64 * NW, [&](const Block& b) { polish_mat_body<double, TileMat<NBL, NW, CH>>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
+
 // the large-QP family: grid (B, gy) of workgroups, one after the other
 template <class F> static void big_grid(int B, int gy, int threads, size_t lds_bytes, const F& body)
 {

@@ -49,6 +49,13 @@ def _worker(rank, world, port, out_dir):
     full = qdist.gather_batch(even, 3 * world)
     want = torch.cat([torch.arange(12, dtype=torch.float64).reshape(3, 4) + 100.0 * r for r in range(world)], 0)
     assert torch.equal(full, want)
+    # the asynchronous form (bench.py: the all_gather of zhat runs beside the backward launches): same tensor after .wait(),
+    # for equal and for unequal slices
+    pend = qdist.gather_batch(even, 3 * world, async_op=True)
+    assert torch.equal(pend.wait(), want)
+    odd = torch.full((hi - lo, 2), float(rank), dtype=torch.float64)
+    got = qdist.gather_batch(odd, nB, async_op=True).wait()
+    assert got.shape == (nB, 2) and torch.equal(got[lo:hi], odd)
     dp_full = p.grad.clone()                        # zero outside this rank's rows
     dist.all_reduce(dp_full, op=dist.ReduceOp.SUM)
     # the solver-level path: zhat, nu, lam, slacks of the whole batch on every rank

@@ -681,6 +681,34 @@ def test_float32_finishing_steps_reach_the_reference_accuracy():
     assert (e_wide < np.maximum(10 * e_ref, 2e-5)).all(), (e_wide, e_ref)
 
 
+@pytest.mark.parametrize("shape,dtype,variant", [((3, 30, 20, 4), torch.float32, 0), ((2, 100, 100, 0), torch.float32, 0),
+                                                 ((3, 30, 20, 4), torch.float64, 0), ((2, 20, 40, 3), torch.float64, 256),
+                                                 ((2, 100, 100, 0), torch.float64, 0), ((2, 30, 50, 5), torch.float64, 0)])
+def test_finishing_stage_kernel_equals_the_host_version(shape, dtype, variant):
+    """qpx_polish (include/qpx.h v6): the finishing stage as ONE kernel -- thread-grid form (float32; float64 with
+    knob 256) and matrix-core tile forms (float64: one wave per QP at 2 tile rows, the chain-wave form at 4 and 7) --
+    against the host-driven version it replaces (KKTFactors._polish_host: the same iteration as float64 tensor ops), from
+    the same start iterate, step by step: equal to rounding, equality constraints included.  The start iterate is the
+    loop kernel's result after THREE iterations, so that the steps have something to do."""
+    from qpth_amd.kkt import KKTFactors
+    B, n, m, q = shape
+    f32 = dtype == torch.float32
+    arrs = problems.prof_qp(B, n, m, q, seed=9, dtype=np.float32 if f32 else np.float64)
+    tQ, tp, tG, th, tA, tb = tens(arrs, dtype, grad=False)
+    with emulated(256, variant):
+        fac = KKTFactors.build(tQ, tG, tA)
+        assert fac.lib.dll.qpx_polish_supported(0 if f32 else 1, n, m, q) == 1
+        for steps in (1, 2):
+            outs = []
+            for fn in (fac.polish, fac._polish_host):
+                res = fac.ipm(tp, th, tb, maxIter=3)
+                res = fn(tp, th, tb, res, steps=steps, refine=1)
+                outs.append([res.zhat.numpy().copy(), res.lam.numpy().copy(), res.slacks.numpy().copy()] + ([res.nu.numpy().copy()] if q else []))
+            tol = 2e-4 if f32 else 1e-9
+            for a_, b_ in zip(*outs):
+                assert np.abs(a_ - b_).max() <= tol * max(1.0, np.abs(b_).max()), (steps, np.abs(a_ - b_).max())
+
+
 @pytest.mark.parametrize("name", ["c3s_b4_n20_m10_q4_f64", "broadcast_b5_n12_m9_q3", "unbatched_n12_m9_q3"])
 def test_float32_data_in_float64_arithmetic(name):
     """float32 tensors at a size the float64 tile kernels serve (QPFunction(refine=None)): the parameters are widened
