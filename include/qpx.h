@@ -111,15 +111,12 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4 (four waves at 4 or 7 tile rows = the chain-wave form, which is the default there); by default the
- * library picks by dtype and size.  Adding 16384 runs the four-wave tile
- * kernels without their chain wave (the round-2 form: every wave owns tile rows and the pivot blocks are not
- * eliminated ahead of the trailing updates) -- kept for same-box A/B.  Adding 32768 runs the pre-factorisation (f64,
- * padded tile rows <= 14) as a symmetric sweep on matrix-core tiles (qpx_tsweep.h) instead of the rank-1 sweep on a
- * 16x16 thread grid: same blob, measured no faster on MI355X (the f64 matrix instruction has no rate advantage over
- * vector FMAs and the padded tiles cost 40 % more flops), so it is opt-in.
+ * library picks by dtype and size.  (Bits 14 and 15 selected two round-3 forms -- the four-wave tile kernels without
+ * their chain wave and a pre-factorisation on matrix-core tiles -- that lost their A/Bs and were deleted in v6.)
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
  * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
- * synchronisation), 0 = one part; bits 20..24 = initial stagger between the side streams in units of 16 us; bit 25 =
+ * synchronisation), 0 = one part; bits 20..23 = initial stagger between the side streams in units of 16 us; bit 24 =
+ * every panel under a diagonal block in a launch of its own (the round-3 order) instead of inside the update launch; bit 25 =
  * the substitutions by four waves per QP instead of sixteen; bit 26 = the mat-vec R z' in front of the factorisation
  * in the caller's stream (the round-3 order) instead of beside it on a helper stream; bit 27 =
  * diagonal blocks eliminated by one wave (the round-3 form) instead of four in the chain-wave form; bit 28 = on the

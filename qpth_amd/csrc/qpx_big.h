@@ -40,7 +40,7 @@ enum BigVec {
     bvONE, bvBQ, bvTB, bvT1, bvNU, bvPQ, bvCount
 };
 enum BigScal { bsTau = 0, bsBtau, bsSigz, bsSigs, bsBres, bsFeasPrev, bsAlphaPrev, bsMu, bsSzdot, bsGt1 = 15 };
-enum BigCtrl { bcStop = 0, bcNnot, bcFloor, bcSt, bcIters, bcFail };
+enum BigCtrl { bcStop = 0, bcNnot, bcFloor, bcSt, bcIters, bcFail, bcFlag };      // bcFlag: index of the last diagonal block eliminated (panel hand-over inside a launch)
 
 // Equality constraints (round 4).  With Lq = chol(Q), Yt = A Lq^-T (neq x nz), S11 = Yt Yt^T = A Q^-1 A^T = L11 L11^T:
 //   K = Q^-1 - Q^-1 A^T S11^-1 A Q^-1 = Lq^-T P Lq^-1,   P = I - Yt^T S11^-1 Yt   (the projector on null(Yt)),
@@ -311,6 +311,7 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
 {
     int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
     if (a.check_stop && ctrl && ctrl[bcStop]) return;
+    if (b.tid == 0 && ctrl && a.k == 0) ctrl[bcFlag] = 0;      // a factorisation starts: no diagonal block of it is published yet
     const T* M = a.M + (size_t)qp * a.sM;
     const int k0 = a.k * kBB;
     const T* dg = a.dg ? a.dg + (size_t)qp * a.sdg + k0 : nullptr;
@@ -352,6 +353,7 @@ template <class T> struct BigGemmArgs {
     int fuse, fuse_k, fail_bit, tile;
     T* W; size_t sW;
     int no_swizzle;              // A/B: plain (qp, tile) grid instead of the XCD-aware one (launcher only)
+    int papply;                  // fused launches of the pipelined form: the tiles BELOW tile (0, 0) in its column wait for W_kk and leave as the finished panel L = tile W_kk^T (+ its mirror) -- no panel launch of its own
     int transb;                  // Bm is given as [k][column] (the product is A Bm, not A Bm^T): rows bkb0.. of Bm, columns of block brb0 + tj (pipelined form only)
     int v1;                      // A/B: the round-3 tile kernel (whole 64-deep k-blocks staged, two workgroups per CU)
 };
@@ -546,6 +548,62 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
         }
     }
     const bool fused = kFuse && a.fuse && tile == 0; // uniform
+    const bool pap = kFuse && a.fuse && a.papply && tj == 0 && ti > 0;      // uniform: a tile of the panel under the diagonal block
+    if constexpr (kFuse) {
+        if (pap) {
+            // The updated tile V never goes to memory: it is staged, the workgroup waits for the W_kk its launch-mate
+            // publishes, and L = V W_kk^T leaves (row-major + mirrored above the diagonal), as the panel launch did.
+            b.sync();
+            T* Vs = lds;                        // [row][k], stride kBL
+            T* Ws = lds + kBB * kBL;            // W_kk [row][k]
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
+                        T v = a.zero_init ? T(0) : cs[x][y][r];
+                        Vs[il * kBL + jl] = fma_(a.alpha, acc[x][y][r], v);
+                        acc[x][y][r] = T(0);
+                    }
+            int* ctrl = a.ctrl + (size_t)qp * a.sctrl;
+            if (b.tid == 0 && !flag_wait(ctrl + bcFlag, a.fuse_k)) ctrl[bcFail] |= a.fail_bit;     // (bounded wait: a failure, never a hang)
+            b.sync();
+            const T* Wg = a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB;
+            for (int e = b.tid; e < kBB * kBB; e += b.nt) Ws[(e >> 6) * kBL + (e & 63)] = Wg[e];
+            b.sync();
+#pragma unroll
+            for (int ch = 0; ch < kBB / kGC; ++ch) {
+                T a0[4], a1[4], b0[4], b1[4];
+                ld4(Vs + (qr + c16) * kBL + ch * kGC + 4 * g, a0);
+                ld4(Vs + (qr + 16 + c16) * kBL + ch * kGC + 4 * g, a1);
+                ld4(Ws + (qc + c16) * kBL + ch * kGC + 4 * g, b0);
+                ld4(Ws + (qc + 16 + c16) * kBL + ch * kGC + 4 * g, b1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    b.mfma16x16x4(a0[s], b0[s], acc[0][0]);
+                    b.mfma16x16x4(a0[s], b1[s], acc[0][1]);
+                    b.mfma16x16x4(a1[s], b0[s], acc[1][0]);
+                    b.mfma16x16x4(a1[s], b1[s], acc[1][1]);
+                }
+            }
+            b.sync();                           // every wave is done with V: its place takes L for the mirrored store
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
+                        C[(size_t)(crb * kBB + il) * a.ldc + ccb * kBB + jl] = acc[x][y][r];
+                        Vs[il * kBL + jl] = acc[x][y][r];
+                    }
+            b.sync();
+            for (int r = w; r < kBB; r += b.nwaves()) C[(size_t)(ccb * kBB + r) * a.ldc + crb * kBB + lane] = Vs[lane * kBL + r];
+            return;
+        }
+    }
     const bool mir = a.mirror && crb != ccb;         // uniform
     const bool staged = fused || mir;
     if (staged) b.sync();                            // every wave is done with the operand buffers
@@ -574,6 +632,10 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
             int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
             big_diag_block<T>(b, [&](int i, int j) { return lds[i * kBL + j]; },
                               a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, lds, lds + kBB * kBL, a.tile);
+            if (a.papply && ctrl) {
+                b.sync();                                    // W_kk is in global memory (a broken-down block too: its QP is flagged)
+                if (b.tid == 0) flag_set(ctrl + bcFlag, a.fuse_k);
+            }
         }
     }
 }

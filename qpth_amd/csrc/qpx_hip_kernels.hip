@@ -8,8 +8,8 @@
 // 3 = kkt/backward, 5 = sweep pre-factorisation (16x16 thread grid),
 // 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only),
 // 10 = batch-mean outer products of shared-parameter gradients, 11 = the large-QP family (qpx_big.h),
-// 12 = sweep pre-factorisation on matrix-core tiles (qpx_tsweep.h, f64 only), 13 = the finishing stage on matrix-core tiles (f64 only;
-// its thread-grid form lives in 7).
+// 13 = the finishing stage on matrix-core tiles (f64 only; its thread-grid form lives in 7).  (12 was the sweep
+// pre-factorisation on matrix-core tiles of round 3: parity-green, never faster than the thread-grid sweep, deleted in round 4.)
 #include <hip/hip_runtime.h>
 
 #include "../../include/qpx.h"
@@ -188,34 +188,6 @@ template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, si
 }
 #define QPX_INSTG(NBL, NS) template int launch_ipm_grid8<QPX_TU_REAL, NBL, NS>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
 QPX_INSTG(2, 1) QPX_INSTG(2, 2) QPX_INSTG(4, 1) QPX_INSTG(4, 2) QPX_INSTG(8, 1) QPX_INSTG(8, 2) QPX_INSTG(13, 2)
-#elif QPX_TU_KERNEL == 12
-// the sweep on matrix-core tiles: one workgroup of NBL / 2 tile waves + the chain wave per QP (at most eight waves)
-template <int NBL> __global__ __launch_bounds__(TSweep<NBL>::NT, 2) void k_tsweep(PrefactorArgs<double> a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    tsweep_body<NBL>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
-}
-template <int NBL> int launch_tsweep(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream)
-{
-    auto kern = k_tsweep<NBL>;
-    static BigLdsFlags big_lds_enabled;
-    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(TSweep<NBL>::NT), lds_bytes, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
-}
-#ifdef QPX_PANEL_PROF
-extern "C" int qpx_sweep_prof_read(unsigned long long* out)      // the chain-form interval counters of THIS translation unit
-{
-    unsigned long long zero[20] = {0};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qpx_chain_prof), sizeof(zero)) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(qpx_chain_prof), zero, sizeof(zero)) != hipSuccess) return -1;
-    return 0;
-}
-#endif
-template int launch_tsweep<8>(const PrefactorArgs<double>&, size_t, void*);
-template int launch_tsweep<12>(const PrefactorArgs<double>&, size_t, void*);
-template int launch_tsweep<14>(const PrefactorArgs<double>&, size_t, void*);
 #elif QPX_TU_KERNEL == 13
 // the finishing stage (qpx_polish) on matrix-core tiles, f64: the forms the dispatcher picks by default
 template <int NBL, int NW, bool CH> __global__ __launch_bounds__(64 * NW, 2) void k_polish_tile(PolishArgs<double> a)
@@ -294,7 +266,7 @@ template <int NBL, int NW, bool kBw, bool CH> int launch_kkt_tile(const KktArgs<
     template int launch_kkt_tile<NBL, NW, true, CH>(const KktArgs<double>&, size_t, void*);
 #if !defined(QPX_TILE_ONLY)
 QPX_INSTK(1, 1, false) QPX_INSTK(2, 1, false) QPX_INSTK(4, 1, false) QPX_INSTK(4, 2, false) QPX_INSTK(7, 2, false)
-QPX_INSTK(7, 4, false) QPX_INSTK(7, 4, true) QPX_INSTK(4, 4, true)
+QPX_INSTK(7, 4, true) QPX_INSTK(4, 4, true)
 #endif
 #define QPX_INSTT(NBL, NW, NS, CH) template int launch_ipm_tile<NBL, NW, NS, CH>(const IpmArgs<double>&, size_t, void*);
 #if defined(QPX_TILE_ONLY)
@@ -302,8 +274,8 @@ QPX_INSTT(7, QPX_TILE_ONLY, 2, QPX_TILE_ONLY == 4)
 #else
 QPX_INSTT(1, 1, 1, false) QPX_INSTT(1, 1, 2, false) QPX_INSTT(1, 1, 4, false) QPX_INSTT(2, 1, 1, false) QPX_INSTT(2, 1, 2, false)
 QPX_INSTT(2, 1, 4, false) QPX_INSTT(4, 1, 1, false) QPX_INSTT(4, 1, 2, false) QPX_INSTT(4, 1, 4, false) QPX_INSTT(4, 2, 1, false)
-QPX_INSTT(4, 2, 2, false) QPX_INSTT(4, 2, 4, false) QPX_INSTT(7, 2, 2, false) QPX_INSTT(7, 2, 4, false) QPX_INSTT(7, 4, 2, false)
-QPX_INSTT(7, 4, 4, false) QPX_INSTT(7, 4, 2, true) QPX_INSTT(7, 4, 4, true) QPX_INSTT(4, 4, 1, true) QPX_INSTT(4, 4, 2, true) QPX_INSTT(4, 4, 4, true)
+QPX_INSTT(4, 2, 2, false) QPX_INSTT(4, 2, 4, false) QPX_INSTT(7, 2, 2, false) QPX_INSTT(7, 2, 4, false)
+QPX_INSTT(7, 4, 2, true) QPX_INSTT(7, 4, 4, true) QPX_INSTT(4, 4, 1, true) QPX_INSTT(4, 4, 2, true) QPX_INSTT(4, 4, 4, true)
 #endif
 #endif
 

@@ -744,38 +744,15 @@ def test_every_loop_kernel_form(dev, variant, shape):
 
 
 # ---------------------------------------------------------------- 5. the bench contract
-# Round 3: the four-wave tile kernels without their chain wave (+16384: the round-2 form; the chain-wave form is the
-# default and is what every other test of this file runs at 65 <= nineq <= 112) and the opt-in pre-factorisation on
-# matrix-core tiles (+32768, qpx_tsweep.h), against the reference's golden vectors and the oracle.
-@pytest.mark.parametrize("variant", [16384, 32768, 32768 + 16384])
-@pytest.mark.parametrize("name", ["c2s_b4_n100_m100_f64", "c3s_b4_n100_m50_q10_f64", "c5s_b6_n64_m64_f64", "c3s_b4_n20_m10_q4_f64"])
-def test_round3_kernel_forms_against_the_reference(dev, variant, name):
-    from qpth_amd import _lib
-    g = load_golden(name)
-    old = _lib.hip().dll.qpx_set_ipm_variant(variant)
-    try:
-        z, grads = run_qpf(golden_inputs(g), g["dl_dz"], dev)
-    finally:
-        _lib.hip().dll.qpx_set_ipm_variant(old)
-    assert rel_err(z, g["zhat"]).max() < TOL
-    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
-        if k in g:
-            assert np.abs(gr - g[k]).max() <= 10 * TOL * max(1.0, np.abs(g[k]).max()), k
-
-
-@pytest.mark.parametrize("variant", [0, 32768])
-def test_round3_forms_full_size_c2(dev, variant):
-    """C2 at its full size (every QP against the oracle) with the chain-wave loop kernel (default) and the tile sweep"""
+def test_full_size_c2_second_seed(dev):
+    """C2 at its full size, a second seed and a random dl_dz: every QP and every gradient against the oracle (the
+    chain-wave loop kernel; its round-3 siblings -- the four-wave form without the chain wave and the pre-factorisation on
+    matrix-core tiles -- were deleted in round 4)."""
     from oracle import qp_oracle as orc
-    from qpth_amd import _lib
     arrs = problems.prof_qp(512, 100, 100, 0, seed=2)
     dl = np.random.RandomState(3).randn(512, 100)
     xr, _, lamr, sr, grads_ref, _ = orc.qp_forward_backward(*arrs, dl, per_qp=True, stall_policy=2)
-    old = _lib.hip().dll.qpx_set_ipm_variant(variant)
-    try:
-        z, grads = run_qpf(arrs, dl, dev)
-    finally:
-        _lib.hip().dll.qpx_set_ipm_variant(old)
+    z, grads = run_qpf(arrs, dl, dev)
     assert rel_err(z, xr).max() < TOL
     for mine, ref in zip(grads, grads_ref):
         if ref is not None and mine is not None:
