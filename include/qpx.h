@@ -115,12 +115,11 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * their chain wave and a pre-factorisation on matrix-core tiles -- that lost their A/Bs and were deleted in v6.)
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
  * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
- * synchronisation), 0 = one part; bits 20..23 = initial stagger between the side streams in units of 16 us; bit 24 =
- * every panel under a diagonal block in a launch of its own (the round-3 order) instead of inside the update launch; bit 25 =
+ * synchronisation), 0 = one part; bits 20..24 = initial stagger between the side streams in units of 16 us; bit 25 =
  * the substitutions by four waves per QP instead of sixteen; bit 26 = the mat-vec R z' in front of the factorisation
  * in the caller's stream (the round-3 order) instead of beside it on a helper stream; bit 27 =
  * diagonal blocks eliminated by one wave (the round-3 form) instead of four in the chain-wave form; bit 28 = on the
- * thread grid; bit 29 = no XCD-aware tile order; bit 30 = the round-3 GEMM tile kernel instead of the pipelined one.
+ * thread grid; bit 29 = no XCD-aware tile order.
  * The knob must not change between qpx_pre_factor and the calls that consume its factors (it selects the
  * layout of `factors` too: ask qpx_factor_elems after setting it).
  * Returns the previous value. */

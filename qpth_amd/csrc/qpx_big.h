@@ -28,6 +28,14 @@
 namespace qpx {
 
 constexpr int kBB = 64;          // block order
+// (round 4) Every matrix of the blob is stored BLOCK by BLOCK: block (rb, cb) of a matrix with `ld` elements per row is
+// the 4096 contiguous elements at ((rb * (ld / 64)) + cb) * 4096, row-major inside.  A workgroup that reads a 64 x 64
+// block -- every GEMM operand, every substitution step -- then reads 32 KB of consecutive memory instead of 64 pieces of
+// 512 bytes a matrix row apart: the family is HBM-bound (profiles/r04c_c4_pmc_*: the whole pass moves 1.9 GB at an
+// effective 3.5 TB/s), and the DRAM pages like the long runs better.
+constexpr int kBE = kBB * kBB;   // elements of a block
+QPX_LAYOUT_HD size_t big_blk(int ld, int rb, int cb) { return ((size_t)rb * (ld / kBB) + cb) * kBE; }
+QPX_LAYOUT_HD size_t big_at(int ld, int i, int j) { return big_blk(ld, i >> 6, j >> 6) + (size_t)(i & 63) * kBB + (j & 63); }
 constexpr int kMaxSide = 3;          // side streams the host may spread the parts of a batch over (qpx_api.inc: big_split)
 constexpr int kBL = kBB + 2;     // LDS row stride of a staged block (elements): 2-way bank conflicts at most
 QPX_LAYOUT_HD int big_pad(int x) { return (x + kBB - 1) / kBB * kBB; }
@@ -40,7 +48,7 @@ enum BigVec {
     bvONE, bvBQ, bvTB, bvT1, bvNU, bvPQ, bvCount
 };
 enum BigScal { bsTau = 0, bsBtau, bsSigz, bsSigs, bsBres, bsFeasPrev, bsAlphaPrev, bsMu, bsSzdot, bsGt1 = 15 };
-enum BigCtrl { bcStop = 0, bcNnot, bcFloor, bcSt, bcIters, bcFail, bcFlag };      // bcFlag: index of the last diagonal block eliminated (panel hand-over inside a launch)
+enum BigCtrl { bcStop = 0, bcNnot, bcFloor, bcSt, bcIters, bcFail };
 
 // Equality constraints (round 4).  With Lq = chol(Q), Yt = A Lq^-T (neq x nz), S11 = Yt Yt^T = A Q^-1 A^T = L11 L11^T:
 //   K = Q^-1 - Q^-1 A^T S11^-1 A Q^-1 = Lq^-T P Lq^-1,   P = I - Yt^T S11^-1 Yt   (the projector on null(Yt)),
@@ -96,7 +104,7 @@ template <class T> QPX_DEV void big_pack_body(const Block& b, const BigPackArgs<
         // Q[j][i] is a strided one: 0.34 ms instead of 0.05 for the 128 matrices of C4)
         if (i < a.rows && j < a.cols) v = S[(size_t)i * a.cols + j];
         else if (a.sym && i == j) v = T(1);
-        D[(size_t)i * a.ldp + j] = v;
+        D[big_at(a.ldp, i, j)] = v;
     }
 }
 
@@ -311,8 +319,7 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
 {
     int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
     if (a.check_stop && ctrl && ctrl[bcStop]) return;
-    if (b.tid == 0 && ctrl && a.k == 0) ctrl[bcFlag] = 0;      // a factorisation starts: no diagonal block of it is published yet
-    const T* M = a.M + (size_t)qp * a.sM;
+    const T* M = a.M + (size_t)qp * a.sM + big_blk(a.ld, a.k, a.k);      // the diagonal block: 4096 consecutive elements
     const int k0 = a.k * kBB;
     const T* dg = a.dg ? a.dg + (size_t)qp * a.sdg + k0 : nullptr;
     T* W = a.W + (size_t)qp * a.sW + (size_t)a.k * 2 * kBB * kBB;
@@ -320,7 +327,7 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
         // the matrix-core form reads the block with one wave: bring it into LDS with all four first (coalesced rows)
         for (int e = b.tid; e < kBB * kBB; e += b.nt) {
             const int i = e >> 6, j = e & 63;
-            T v = M[(size_t)(k0 + i) * a.ld + k0 + j];
+            T v = M[e];
             if (dg && i == j) v += dg[i];
             lds[i * kBL + j] = v;
         }
@@ -329,7 +336,7 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
         return;
     }
     big_diag_block<T>(b, [&](int i, int j) {
-        T v = M[(size_t)(k0 + i) * a.ld + k0 + j];
+        T v = M[i * kBB + j];
         if (dg && i == j) v += dg[i];
         return v;
     }, W, ctrl, a.fail_bit, lds, lds + kBB * kBL, 0);
@@ -353,11 +360,8 @@ template <class T> struct BigGemmArgs {
     int fuse, fuse_k, fail_bit, tile;
     T* W; size_t sW;
     int no_swizzle;              // A/B: plain (qp, tile) grid instead of the XCD-aware one (launcher only)
-    int papply;                  // fused launches of the pipelined form: the tiles BELOW tile (0, 0) in its column wait for W_kk and leave as the finished panel L = tile W_kk^T (+ its mirror) -- no panel launch of its own
     int transb;                  // Bm is given as [k][column] (the product is A Bm, not A Bm^T): rows bkb0.. of Bm, columns of block brb0 + tj (pipelined form only)
-    int v1;                      // A/B: the round-3 tile kernel (whole 64-deep k-blocks staged, two workgroups per CU)
 };
-QPX_LAYOUT_HD size_t big_gemm_lds_elems() { return (size_t)2 * kBB * kBL; }
 // pipelined form (big_gemm2_body): k-chunks of 16, operands row-major [row][k] with a row stride of kGL elements,
 // two buffers each; a fused launch also needs the staged tile + the diagonal-block scratch (big_diag_block)
 constexpr int kGC = 16;
@@ -372,99 +376,7 @@ template <class T> QPX_LAYOUT_HD size_t big_gemm2_lds_elems(bool fused, bool mir
     return e;
 }
 
-template <class T> QPX_DEV void big_gemm_body(const Block& b, const BigGemmArgs<T>& a, int qp, int tile, T* lds)
-{
-    if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
-    const int ti = tile / a.ntj, tj = tile - ti * a.ntj;
-    const int crb = a.crb0 + ti, ccb = a.ccb0 + tj;
-    if (a.lower && crb < ccb) return;
-    T* As = lds;                 // [k][row]  (k-major: the MFMA operand of lane (g, c) is As[4 s + g][c + 16 rt])
-    T* Bs = As + kBB * kBL;
-    const T* Ag = a.A + (size_t)qp * a.sA + (size_t)(a.arb0 + ti) * kBB * a.lda;
-    const T* Bg = a.Bm + (size_t)qp * a.sB + (size_t)(a.brb0 + tj) * kBB * a.ldb;
-    const int lane = b.lane(), w = b.uniform(b.wave()), g = lane >> 4, c16 = lane & 15;
-    const int qr = (w >> 1) * 32, qc = (w & 1) * 32;         // this wave's 32 x 32 quadrant
-    T acc[2][2][4];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[x][y][r] = T(0);
-    T* C = a.C + (size_t)qp * a.sC;
-    const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs : C;
-    const int ldcs = a.Cs ? a.ldcs : a.ldc;
-    // The workgroup's life is a chain of memory latencies (operands of a k-block -> LDS -> matrix cores, then the
-    // tile of C): the tile of C is requested first, and the operands of k-block kb + 1 are requested (into
-    // registers) before the matrix instructions of k-block kb are issued, so both fly under them.
-    T cs[2][2][4];
-    if (!a.zero_init) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = crb * kBB + qr + 16 * x + Block::mfma_row(T(0), g, r), j = ccb * kBB + qc + 16 * y + c16;
-                    cs[x][y][r] = Cs[(size_t)i * ldcs + j];
-                }
-    }
-    constexpr int kPer = kBB * kBB / 256;             // staged elements per thread and operand (256 threads)
-    T pa[kPer], pb[kPer];
-    const int sr = b.tid >> 6, sk = b.tid & 63;        // a wave stages one row (64 consecutive k) per step
-    auto fetch = [&](int kb) {
-#pragma unroll
-        for (int u = 0; u < kPer; ++u) {
-            pa[u] = Ag[(size_t)(sr + 4 * u) * a.lda + (a.akb0 + kb) * kBB + sk];
-            pb[u] = Bg[(size_t)(sr + 4 * u) * a.ldb + (a.bkb0 + kb) * kBB + sk];
-        }
-    };
-    fetch(0);
-    for (int kb = 0; kb < a.nk; ++kb) {
-        b.sync();
-#pragma unroll
-        for (int u = 0; u < kPer; ++u) {
-            As[sk * kBL + sr + 4 * u] = pa[u];
-            Bs[sk * kBL + sr + 4 * u] = pb[u];
-        }
-        b.sync();
-        if (kb + 1 < a.nk) fetch(kb + 1);
-#pragma unroll 4
-        for (int s = 0; s < kBB / 4; ++s) {
-            const T a0 = As[(4 * s + g) * kBL + qr + c16], a1 = As[(4 * s + g) * kBL + qr + 16 + c16];
-            const T b0 = Bs[(4 * s + g) * kBL + qc + c16], b1 = Bs[(4 * s + g) * kBL + qc + 16 + c16];
-            b.mfma16x16x4(a0, b0, acc[0][0]);
-            b.mfma16x16x4(a0, b1, acc[0][1]);
-            b.mfma16x16x4(a1, b0, acc[1][0]);
-            b.mfma16x16x4(a1, b1, acc[1][1]);
-        }
-    }
-    const bool fused = a.fuse && tile == 0;          // uniform
-    if (fused) b.sync();                             // every wave is done with the operand tiles in LDS
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
-                const int i = crb * kBB + il, j = ccb * kBB + jl;
-                T v = a.zero_init ? T(0) : cs[x][y][r];
-                if (a.dg && i == j) v += a.dg[(size_t)qp * a.sdg + i];
-                v = fma_(a.alpha, acc[x][y][r], v);
-                C[(size_t)i * a.ldc + j] = v;
-                if (a.mirror && crb != ccb) C[(size_t)j * a.ldc + i] = v;
-                if (fused) As[il * kBL + jl] = v;
-            }
-    if (fused) {
-        b.sync();
-        int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
-        big_diag_block<T>(b, [&](int i, int j) { return As[i * kBL + j]; },
-                          a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, As, Bs, a.tile);
-    }
-}
-
-// The same tile product, PIPELINED (round 4; the default).  The round-3 kernel staged whole 64-deep k-blocks (67 KB of
+// The tile product, PIPELINED (round 4).  The round-3 kernel staged whole 64-deep k-blocks (67 KB of
 // LDS: two workgroups per CU) and most of its launches are one to four rounds of workgroups, each a chain of memory
 // latencies (operands -> LDS -> matrix cores -> C).  Here the k-dimension moves in chunks of 16 through two small
 // buffers (37 KB: four workgroups per CU), one barrier per chunk, the next chunk's global loads in flight under the
@@ -485,9 +397,10 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
     constexpr int LD = big_gl<T>();
     T* As = lds;                         // [buf][row][LD]
     T* Bs = lds + 2 * kBB * LD;
-    const T* Ag = a.A + (size_t)qp * a.sA + (size_t)(a.arb0 + ti) * kBB * a.lda + (size_t)a.akb0 * kBB;
-    const T* Bg = a.transb ? a.Bm + (size_t)qp * a.sB + (size_t)a.bkb0 * kBB * a.ldb + (size_t)(a.brb0 + tj) * kBB
-                           : a.Bm + (size_t)qp * a.sB + (size_t)(a.brb0 + tj) * kBB * a.ldb + (size_t)a.bkb0 * kBB;
+    // operand blocks of k-block kb: A (arb0 + ti, akb0 + kb); B (brb0 + tj, bkb0 + kb), or (bkb0 + kb, brb0 + tj) when given as [k][column]
+    const T* Ag = a.A + (size_t)qp * a.sA + big_blk(a.lda, a.arb0 + ti, a.akb0);
+    const T* Bg = a.Bm + (size_t)qp * a.sB + (a.transb ? big_blk(a.ldb, a.bkb0, a.brb0 + tj) : big_blk(a.ldb, a.brb0 + tj, a.bkb0));
+    const size_t bstep = a.transb ? (size_t)(a.ldb / kBB) * kBE : (size_t)kBE;        // from one k-block of B to the next
     const int lane = b.lane(), w = b.uniform(b.wave()), g = lane >> 4, c16 = lane & 15;
     const int qr = (w >> 1) * 32, qc = (w & 1) * 32;         // this wave's 32 x 32 quadrant
     T acc[2][2][4];
@@ -497,9 +410,9 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[x][y][r] = T(0);
-    T* C = a.C + (size_t)qp * a.sC;
-    const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs : C;
-    const int ldcs = a.Cs ? a.ldcs : a.ldc;
+    T* Cq = a.C + (size_t)qp * a.sC;
+    T* C = Cq + big_blk(a.ldc, crb, ccb);                                      // this tile: 4096 consecutive elements
+    const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs + big_blk(a.ldcs, crb, ccb) : C;
     T cs[2][2][4];
     if (!a.zero_init) {
 #pragma unroll
@@ -507,19 +420,18 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = crb * kBB + qr + 16 * x + Block::mfma_row(T(0), g, r), j = ccb * kBB + qc + 16 * y + c16;
-                    cs[x][y][r] = Cs[(size_t)i * ldcs + j];
-                }
+                for (int r = 0; r < 4; ++r)
+                    cs[x][y][r] = Cs[(qr + 16 * x + Block::mfma_row(T(0), g, r)) * kBB + qc + 16 * y + c16];
     }
     // staging coordinates: A (and B as [column][k]): row sr, k 4 sq ..; B as [k][column]: k-row tr, columns 4 tq ..
     const int sr = b.tid >> 2, sq = b.tid & 3, tr = b.tid >> 4, tq = b.tid & 15;
     const int nch = a.nk * (kBB / kGC);
     T pa[4], pb[4];
     auto fetch = [&](int ch) {
-        ld4(Ag + (size_t)sr * a.lda + ch * kGC + 4 * sq, pa);
-        if (a.transb) ld4(Bg + (size_t)(ch * kGC + tr) * a.ldb + 4 * tq, pb);
-        else ld4(Bg + (size_t)sr * a.ldb + ch * kGC + 4 * sq, pb);
+        const int kb = ch >> 2, ko = (ch & 3) * kGC;                           // k-block, offset of the chunk inside it
+        ld4(Ag + (size_t)kb * kBE + sr * kBB + ko + 4 * sq, pa);
+        if (a.transb) ld4(Bg + (size_t)kb * bstep + (ko + tr) * kBB + 4 * tq, pb);
+        else ld4(Bg + (size_t)kb * bstep + sr * kBB + ko + 4 * sq, pb);
     };
     fetch(0);
     for (int ch = 0; ch < nch; ++ch) {
@@ -548,62 +460,6 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
         }
     }
     const bool fused = kFuse && a.fuse && tile == 0; // uniform
-    const bool pap = kFuse && a.fuse && a.papply && tj == 0 && ti > 0;      // uniform: a tile of the panel under the diagonal block
-    if constexpr (kFuse) {
-        if (pap) {
-            // The updated tile V never goes to memory: it is staged, the workgroup waits for the W_kk its launch-mate
-            // publishes, and L = V W_kk^T leaves (row-major + mirrored above the diagonal), as the panel launch did.
-            b.sync();
-            T* Vs = lds;                        // [row][k], stride kBL
-            T* Ws = lds + kBB * kBL;            // W_kk [row][k]
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
-                        T v = a.zero_init ? T(0) : cs[x][y][r];
-                        Vs[il * kBL + jl] = fma_(a.alpha, acc[x][y][r], v);
-                        acc[x][y][r] = T(0);
-                    }
-            int* ctrl = a.ctrl + (size_t)qp * a.sctrl;
-            if (b.tid == 0 && !flag_wait(ctrl + bcFlag, a.fuse_k)) ctrl[bcFail] |= a.fail_bit;     // (bounded wait: a failure, never a hang)
-            b.sync();
-            const T* Wg = a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB;
-            for (int e = b.tid; e < kBB * kBB; e += b.nt) Ws[(e >> 6) * kBL + (e & 63)] = Wg[e];
-            b.sync();
-#pragma unroll
-            for (int ch = 0; ch < kBB / kGC; ++ch) {
-                T a0[4], a1[4], b0[4], b1[4];
-                ld4(Vs + (qr + c16) * kBL + ch * kGC + 4 * g, a0);
-                ld4(Vs + (qr + 16 + c16) * kBL + ch * kGC + 4 * g, a1);
-                ld4(Ws + (qc + c16) * kBL + ch * kGC + 4 * g, b0);
-                ld4(Ws + (qc + 16 + c16) * kBL + ch * kGC + 4 * g, b1);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    b.mfma16x16x4(a0[s], b0[s], acc[0][0]);
-                    b.mfma16x16x4(a0[s], b1[s], acc[0][1]);
-                    b.mfma16x16x4(a1[s], b0[s], acc[1][0]);
-                    b.mfma16x16x4(a1[s], b1[s], acc[1][1]);
-                }
-            }
-            b.sync();                           // every wave is done with V: its place takes L for the mirrored store
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
-                        C[(size_t)(crb * kBB + il) * a.ldc + ccb * kBB + jl] = acc[x][y][r];
-                        Vs[il * kBL + jl] = acc[x][y][r];
-                    }
-            b.sync();
-            for (int r = w; r < kBB; r += b.nwaves()) C[(size_t)(ccb * kBB + r) * a.ldc + crb * kBB + lane] = Vs[lane * kBL + r];
-            return;
-        }
-    }
     const bool mir = a.mirror && crb != ccb;         // uniform
     const bool staged = fused || mir;
     if (staged) b.sync();                            // every wave is done with the operand buffers
@@ -618,24 +474,21 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
                 T v = a.zero_init ? T(0) : cs[x][y][r];
                 if (a.dg && i == j) v += a.dg[(size_t)qp * a.sdg + i];
                 v = fma_(a.alpha, acc[x][y][r], v);
-                C[(size_t)i * a.ldc + j] = v;
+                C[il * kBB + jl] = v;
                 if (staged) lds[il * kBL + jl] = v;
             }
     if (!staged) return;
     b.sync();
     if (mir) {
         // row r of the transposed tile = column r of the staged one
-        for (int r = w; r < kBB; r += b.nwaves()) C[(size_t)(ccb * kBB + r) * a.ldc + crb * kBB + lane] = lds[lane * kBL + r];
+        T* Cm = Cq + big_blk(a.ldc, ccb, crb);
+        for (int r = w; r < kBB; r += b.nwaves()) Cm[r * kBB + lane] = lds[lane * kBL + r];
     }
     if constexpr (kFuse) {
         if (fused) {
             int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
             big_diag_block<T>(b, [&](int i, int j) { return lds[i * kBL + j]; },
                               a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, lds, lds + kBB * kBL, a.tile);
-            if (a.papply && ctrl) {
-                b.sync();                                    // W_kk is in global memory (a broken-down block too: its QP is flagged)
-                if (b.tid == 0) flag_set(ctrl + bcFlag, a.fuse_k);
-            }
         }
     }
 }
@@ -693,13 +546,14 @@ template <class T, int NW> QPX_DEV void big_trsv_body(const Block& b, const BigT
         {
             // rows c of the stored matrix (L^T above the diagonal for dir 0, L below it for dir 1), element k0 + lane;
             // eight independent loads in flight per lane
-            const T* col = M + k0 + lane;
+            // (row c of block column k: block (c / 64, k), its row c % 64 -- consecutive rows are consecutive memory)
+            auto at = [&](int c) { return M[big_blk(a.ld, c >> 6, k) + (size_t)(c & 63) * kBB + lane]; };
             T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
             int c = c0 + w;
             for (; c + 7 * NW < c1; c += 8 * NW) {
-                const T m0 = col[(size_t)c * a.ld], m1 = col[(size_t)(c + NW) * a.ld], m2 = col[(size_t)(c + 2 * NW) * a.ld];
-                const T m3 = col[(size_t)(c + 3 * NW) * a.ld], m4 = col[(size_t)(c + 4 * NW) * a.ld], m5 = col[(size_t)(c + 5 * NW) * a.ld];
-                const T m6 = col[(size_t)(c + 6 * NW) * a.ld], m7 = col[(size_t)(c + 7 * NW) * a.ld];
+                const T m0 = at(c), m1 = at(c + NW), m2 = at(c + 2 * NW);
+                const T m3 = at(c + 3 * NW), m4 = at(c + 4 * NW), m5 = at(c + 5 * NW);
+                const T m6 = at(c + 6 * NW), m7 = at(c + 7 * NW);
                 a0 = fma_(m0, xs[c], a0);
                 a1 = fma_(m1, xs[c + NW], a1);
                 a2 = fma_(m2, xs[c + 2 * NW], a2);
@@ -709,7 +563,7 @@ template <class T, int NW> QPX_DEV void big_trsv_body(const Block& b, const BigT
                 a6 = fma_(m6, xs[c + 6 * NW], a6);
                 a7 = fma_(m7, xs[c + 7 * NW], a7);
             }
-            for (; c < c1; c += NW) a0 = fma_(col[(size_t)c * a.ld], xs[c], a0);
+            for (; c < c1; c += NW) a0 = fma_(at(c), xs[c], a0);
             part[w * kBB + lane] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
         }
         b.sync();
@@ -753,9 +607,9 @@ template <class T> QPX_DEV void big_gemv_body(const Block& b, const BigGemvArgs<
         for (int r = w; r < kBB; r += nw) {
             const int i = chunk * kBB + r;
             if (i >= a.rows) break;
-            const T* row = M + (size_t)i * a.ld;
+            const T* row = M + big_blk(a.ld, i >> 6, 0) + (size_t)(i & 63) * kBB + lane;      // + a block per 64 columns
             T acc = T(0);
-            for (int c = lane; c < a.cols; c += kWave) acc = fma_(row[c], x[c], acc);
+            for (int c = lane, cb = 0; c < a.cols; c += kWave, ++cb) acc = fma_(row[(size_t)cb * kBE], x[c], acc);
             acc = wave_sum(b, acc);
             if (lane == 0) y[i] = fma_(a.alpha, acc, y0 ? a.beta * y0[i] : T(0));
         }
@@ -764,7 +618,7 @@ template <class T> QPX_DEV void big_gemv_body(const Block& b, const BigGemvArgs<
         const int j = chunk * kBB + lane;
         T acc = T(0);
         if (j < a.cols)
-            for (int i = w; i < a.rows; i += nw) acc = fma_(M[(size_t)i * a.ld + j], x[i], acc);
+            for (int i = w; i < a.rows; i += nw) acc = fma_(M[big_blk(a.ld, i >> 6, chunk) + (size_t)(i & 63) * kBB + lane], x[i], acc);
         lds[w * kWave + lane] = acc;
         b.sync();
         if (w == 0 && j < a.cols) {

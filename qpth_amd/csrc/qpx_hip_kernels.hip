@@ -315,15 +315,8 @@ template <class T> QPX_DEV void big_gemm_where(const BigGemmArgs<T>& a, int ntil
         }
     }
 }
-template <class T> __global__ __launch_bounds__(256) void k_big_gemm(BigGemmArgs<T> a, int ntiles, int swz)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    int qp, tile;
-    big_gemm_where(a, ntiles, swz, qp, tile);
-    big_gemm_body<T>(b, a, qp, tile, reinterpret_cast<T*>(qpx_smem));
-}
-// the pipelined form (round 4, default): 37 KB of LDS and <= 128 registers, four workgroups per CU
+// the tile product, pipelined (round 4): 37 KB of LDS and <= 128 registers, four workgroups per CU (a launch that also
+// eliminates a diagonal block: 71 KB, two)
 template <class T, bool kFuse> __global__ __launch_bounds__(256, (kFuse ? 2 : 4)) void k_big_gemm2(BigGemmArgs<T> a, int ntiles, int swz)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
@@ -368,14 +361,8 @@ template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void* s)
 template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_panel<T>, a, a.B, 1, 256, big_panel_lds_elems() * sizeof(T), s, f); }
 template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* s)
 {
-    static BigLdsFlags f, f2;
+    static BigLdsFlags f2;
     const int ntiles = a.nti * a.ntj, swz = (a.B % 8 == 0 && ntiles > 1 && a.fuse && !a.no_swizzle) ? 1 : 0;   // measured (r02i): the trailing updates gain 3 %, R = Zt Zt^T (half its tiles empty) loses 30 %
-    if (a.v1 && !a.transb) {
-        const size_t lds = big_gemm_lds_elems() * sizeof(T);
-        if (allow_big_lds(k_big_gemm<T>, lds, f)) return QPX_ERR_LAUNCH;
-        hipLaunchKernelGGL(k_big_gemm<T>, swz ? dim3(a.B * ntiles) : dim3(a.B, ntiles), dim3(256), lds, (hipStream_t)s, a, ntiles, swz);
-        return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
-    }
     const size_t lds = big_gemm2_lds_elems<T>(a.fuse != 0, a.mirror != 0) * sizeof(T);
     if (a.fuse) {
         if (allow_big_lds(k_big_gemm2<T, true>, lds, f2)) return QPX_ERR_LAUNCH;

@@ -218,24 +218,6 @@ struct Block {
     static QPX_HD int mfma_row(float, int g, int r) { return 4 * g + r; }
 };
 
-// A one-word flag in global memory between workgroups of ONE launch (the large-QP family: the workgroup that eliminates a
-// diagonal block publishes W_kk, the workgroups of the panel below it wait for it).  flag_set: the caller has made the
-// workgroup's global writes complete (Block::sync) -- release at agent scope; flag_wait: polls with acquire loads (the
-// CU's vector L1 is invalidated by the acquire), BOUNDED: false after ~1 s instead of a hung GPU.
-QPX_DEV void flag_set(int* p, int v)
-{
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-QPX_DEV bool flag_wait(const int* p, int v)
-{
-    for (int i = 0; i < (1 << 22); ++i) {
-        if (__hip_atomic_load(const_cast<int*>(p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == v) return true;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    return false;
-}
-
 QPX_DEV void atomic_add_(float* p, float v) { atomicAdd(p, v); }
 QPX_DEV void atomic_add_(double* p, double v) { atomicAdd(p, v); }
 

@@ -375,10 +375,7 @@ template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void*)
 }
 template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void*)
 {
-    if (a.v1 && !a.transb)
-        big_grid(a.B, a.nti * a.ntj, 256, big_gemm_lds_elems() * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemm_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
-    else
-        big_grid(a.B, a.nti * a.ntj, 256, big_gemm2_lds_elems<T>(a.fuse != 0, a.mirror != 0) * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemm2_body<T, true>(b, a, qp, y, reinterpret_cast<T*>(l)); });
+    big_grid(a.B, a.nti * a.ntj, 256, big_gemm2_lds_elems<T>(a.fuse != 0, a.mirror != 0) * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemm2_body<T, true>(b, a, qp, y, reinterpret_cast<T*>(l)); });
     return QPX_OK;
 }
 template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void*)

@@ -192,10 +192,6 @@ struct Block {
     static int mfma_row(float, int g, int r) { return 4 * g + r; }
 };
 
-// workgroups run one after the other in the emulation (the setter's first): the flag is there or it never will be
-inline void flag_set(int* p, int v) { *p = v; }
-inline bool flag_wait(const int* p, int v) { return *p == v; }
-
 // workgroups run one after the other in the emulation: a plain add is the atomic
 inline void atomic_add_(float* p, float v) { *p += v; }
 inline void atomic_add_(double* p, double v) { *p += v; }

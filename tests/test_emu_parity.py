@@ -334,9 +334,8 @@ def test_edge_shapes_match_the_reference(name):
 # ---------------------------------------------------------------- round 2: the large-QP family (qpx_big.h)
 @pytest.mark.parametrize("shape,dtype,knob", [((1, 66, 70, 0), torch.float64, 3), ((1, 20, 70, 0), torch.float32, 3),
                                               ((3, 20, 70, 0), torch.float64, 3 + (3 << 16)),
-                                              ((1, 66, 70, 0), torch.float64, 3 + (1 << 30)), ((1, 20, 70, 0), torch.float32, 3 + (1 << 30)),
                                               ((1, 66, 70, 0), torch.float64, 3 + (1 << 27)), ((1, 66, 70, 0), torch.float64, 3 + (1 << 28)),
-                                              ((1, 66, 70, 0), torch.float64, 3 + (1 << 25) + (1 << 26)), ((2, 130, 200, 0), torch.float64, 3), ((1, 130, 200, 0), torch.float64, 3 + (1 << 24)),
+                                              ((1, 66, 70, 0), torch.float64, 3 + (1 << 25) + (1 << 26)), ((2, 130, 200, 0), torch.float64, 3),
                                               ((2, 66, 70, 5), torch.float64, 3), ((1, 130, 40, 70), torch.float64, 3),
                                               ((2, 66, 70, 5), torch.float32, 3), ((2, 66, 70, 5), torch.float64, 3 + (2 << 16))])
 def test_large_qp_family(shape, dtype, knob):
@@ -344,10 +343,10 @@ def test_large_qp_family(shape, dtype, knob):
     updates on 64 x 64 blocks, matrices in HBM).  Forced here (knob 3) at sizes of two and three blocks so that the
     blocked code paths run on the emulator: zhat and every gradient against the oracle.  Third case: the batch
     split into three parts (knob bits 16..19), as the host does on the GPU to overlap the parts on side streams.  Knob
-    bit 30: the round-3 GEMM tile kernel instead of the pipelined one; bits 27 / 28: the diagonal blocks by one wave /
+    bits 27 / 28: the diagonal blocks by one wave /
     on the thread grid instead of the chain-wave form; bits 25 / 26: four-wave substitutions and R z' in front of the
-    factorisation, the round-3 order; bit 24: a launch of its own for every panel (all kept for same-box A/B; nineq = 200:
-    four blocks, so that the panels finished inside the update launches -- the flag hand-over -- run in both launch shapes).  Round 4: equality constraints
+    factorisation, the round-3 order (all kept for same-box A/B; nineq = 200: four blocks, both shapes of the
+    update launches).  Round 4: equality constraints
     (neq = 5: one block; neq = 70: two blocks, the blocked solves with L11), all six gradients.  (The float32 KERNELS of
     this family -- QPFunction(refine=k) on float32 tensors; the default is float64 arithmetic -- lose gradient accuracy
     with equality constraints when nz < nineq: 0.18 relative at nz = 30, nineq = 70, neq = 3 on this generator.)"""
@@ -444,6 +443,83 @@ def test_backward_from_external_solutions(name):
         if k in g:
             assert t.grad.shape == g[k].shape, k
             assert np.abs(t.grad.numpy() - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
+
+
+def test_cvxpy_adapter_against_a_stand_in_for_cvxpy(monkeypatch):
+    """solvers/external.py:_cvxpy_solve is written against cvxpy's public API, and cvxpy is not in the image (VERDICT r3:
+    the adapter had never executed).  A stand-in module with the handful of names it uses -- Variable, quad_form,
+    psd_wrap, Minimize, Problem, `G @ z <= h`, `A @ z == b`, .value / .dual_value / .status -- whose Problem.solve() is the
+    oracle and whose dual_value follows cvxpy's documented conventions (an inequality's dual is its non-negative
+    multiplier; an equality's is the multiplier of A z - b in the Lagrangian, which is the reference's nu,
+    qpth/solvers/cvxpy.py:24-27): QPFunction(solver=QPSolvers.CVXPY) through it must reproduce the reference's zhat and
+    gradients.  What this pins is the adapter's plumbing and sign handling, not cvxpy itself."""
+    import sys
+    import types
+    from qpth_amd.qp import QPSolvers
+    from qpth_amd.solvers import external
+
+    class Expr:
+        __array_ufunc__ = None          # (as cvxpy's expressions: numpy defers `ndarray @ expr` to __rmatmul__)
+
+        def __init__(self, kind, **kw):
+            self.kind, self.__dict__ = kind, dict(kind=kind, **kw)
+
+    class Variable:
+        __array_ufunc__ = None
+
+        def __init__(self, n):
+            self.n, self.value = n, None
+
+        def __rmatmul__(self, M):
+            return Expr("affine", M=np.asarray(M), var=self)
+
+    def _cmp(kind):
+        def f(self, rhs):
+            c = Expr(kind, M=self.M, var=self.var, rhs=np.asarray(rhs))
+            c.dual_value = None
+            return c
+        return f
+    Expr.__le__ = _cmp("le")
+    Expr.__eq__ = _cmp("eq")
+    Expr.__hash__ = object.__hash__
+    Expr.__add__ = lambda self, other: Expr("sum", terms=[self, other])
+    Expr.__rmul__ = lambda self, c: Expr("scaled", c=c, e=self)
+
+    fake = types.ModuleType("cvxpy")
+    fake.Variable = Variable
+    fake.psd_wrap = lambda Q: np.asarray(Q)
+    fake.quad_form = lambda z, Q: Expr("quad", Q=np.asarray(Q), var=z)
+    fake.Minimize = lambda e: e
+
+    class Problem:
+        def __init__(self, obj, cons):
+            self.obj, self.cons, self.status = obj, cons, None
+
+        def solve(self):
+            quad = [t.e for t in self.obj.terms if t.kind == "scaled"][0]
+            lin = [t for t in self.obj.terms if t.kind == "affine"][0]
+            Q, p, z = quad.Q, lin.M, quad.var
+            ineq = [c for c in self.cons if c.kind == "le"][0]
+            eqs = [c for c in self.cons if c.kind == "eq"]
+            A = eqs[0].M[None] if eqs else np.zeros(0)
+            b = eqs[0].rhs[None] if eqs else np.zeros(0)
+            x, y, lam, s, info = orc.OracleQP(Q[None], p[None], ineq.M[None], ineq.rhs[None], A, b).forward()
+            z.value = x[0]
+            ineq.dual_value = lam[0]
+            if eqs:
+                eqs[0].dual_value = y[0]
+            self.status = "optimal"
+    fake.Problem = Problem
+    monkeypatch.setitem(sys.modules, "cvxpy", fake)
+    external.set_solver(None)
+    g = load_golden("c3s_b4_n20_m10_q4_f64")
+    tq = tens([g[k] for k in ("Q", "p", "G", "h", "A", "b")])
+    with emulated():
+        z = QPFunction(verbose=-1, solver=QPSolvers.CVXPY)(*tq)
+        z.backward(torch.tensor(g["dl_dz"]))
+    assert rel_err(z.detach().numpy(), g["zhat"]).max() < TOL
+    for k, t in zip(("dQ", "dp", "dG", "dh", "dA", "db"), tq):
+        assert np.abs(t.grad.numpy() - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
 
 
 def test_external_solver_without_cvxpy_fails_loudly():
