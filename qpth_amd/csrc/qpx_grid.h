@@ -1391,6 +1391,54 @@ QPX_DEV void resid_cols(const Block& blk, T* out, const T* base, int cols, const
         out[c] = (T)((a0 + a1) + (a2 + a3));
     }
 }
+// The same sums by ALL nt threads of the workgroup (the thread-per-column form above keeps cols of them busy -- 100 of 256
+// at C2 -- each walking every row with four loads in flight): the rows of each matrix are dealt over G = nt / cols groups
+// of threads, eight loads in flight per thread, and the groups' partial sums meet in `part` (nt doubles of LDS) in a
+// fixed order.  Two barriers inside (`sync`); out may be base.
+template <class T, class V, class Sync>
+QPX_DEV void resid_cols_all(const Block& blk, int nt, T* out, const T* base, int cols, const T* M1, const V* v1, int r1,
+                            const T* M2, const V* v2, int r2, const T* M3, const V* v3, int r3, double* part, Sync&& sync)
+{
+    const int G = nt / cols;
+    if (G < 2) {                                     // more columns than half the threads: the thread-per-column form
+        resid_cols<T, V>(blk, out, base, cols, M1, v1, r1, M2, v2, r2, M3, v3, r3);
+        sync();
+        return;
+    }
+    const int c = blk.tid % cols, grp = blk.tid / cols;
+    if (grp < G) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+        auto add = [&](const T* M, const V* v, int rows) {
+            const int lo = (int)((long long)rows * grp / G), hi = (int)((long long)rows * (grp + 1) / G);
+            const T* col = M + c;
+            int r = lo;
+            for (; r + 8 <= hi; r += 8) {
+                const T m0 = col[(size_t)r * cols], m1 = col[(size_t)(r + 1) * cols], m2 = col[(size_t)(r + 2) * cols], m3 = col[(size_t)(r + 3) * cols];
+                const T m4 = col[(size_t)(r + 4) * cols], m5 = col[(size_t)(r + 5) * cols], m6 = col[(size_t)(r + 6) * cols], m7 = col[(size_t)(r + 7) * cols];
+                a0 = fma_((double)m0, (double)v[r], a0);
+                a1 = fma_((double)m1, (double)v[r + 1], a1);
+                a2 = fma_((double)m2, (double)v[r + 2], a2);
+                a3 = fma_((double)m3, (double)v[r + 3], a3);
+                a4 = fma_((double)m4, (double)v[r + 4], a4);
+                a5 = fma_((double)m5, (double)v[r + 5], a5);
+                a6 = fma_((double)m6, (double)v[r + 6], a6);
+                a7 = fma_((double)m7, (double)v[r + 7], a7);
+            }
+            for (; r < hi; ++r) a0 = fma_((double)col[(size_t)r * cols], (double)v[r], a0);
+        };
+        add(M1, v1, r1);
+        if (M2) add(M2, v2, r2);
+        if (M3) add(M3, v3, r3);
+        part[grp * cols + c] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    }
+    sync();
+    if (blk.tid < cols) {
+        double sum = base ? (double)base[blk.tid] : 0.0;
+        for (int g2 = 0; g2 < G; ++g2) sum += part[g2 * cols + blk.tid];
+        out[blk.tid] = (T)sum;
+    }
+    sync();
+}
 // out[r] = sign * (b1[r] - b2[r] + sum_c M[r][c] v[c])   (r < rows; b1 / b2 may be null): row dots in double, one rounding
 template <class T, class V, class B1>
 QPX_DEV void resid_rows(const Block& blk, T* out, const B1* b1, const T* b2, const T* M, const V* v, int rows, int cols, double sign)
@@ -1465,7 +1513,8 @@ QPX_DEV void polish_mat_role(const Block& b, const PolishArgs<T>& a, int qp, T* 
     double* bzd = bsd + v;
     double* byd = bzd + v;
     double* sc = byd + v; // 16 scalars
-    T* scr = reinterpret_cast<T*>(sc + 16);     // Mat::scratch_elems()
+    double* part = sc + 16;                     // NT partial sums of the column products (resid_cols_all)
+    T* scr = reinterpret_cast<T*>(part + NT);   // Mat::scratch_elems()
     enum { kMu = 0, kTot, kBest, kBetter, kAlpha };
 
     const T* Qg = a.Q + (size_t)qp * a.sQ;
@@ -1495,20 +1544,20 @@ QPX_DEV void polish_mat_role(const Block& b, const PolishArgs<T>& a, int qp, T* 
     typename Mat::Regs E;
     bool ok = true;
     // one application of the condensed KKT inverse with the factor in E (kkt_mat_role::apply)
+    auto wgsync = [&]() { Mat::sync(b); };
+    const T* nullT = nullptr;
     auto apply = [&](const T* rX, const T* rY, T* rH, T* oZ, T* oX, T* oY) {
-        block_matTvec<T, 1>(b, rH, F + lay.MT, rX, n, m);
+        resid_cols_all<T, T>(b, NT, rH, rH, m, F + lay.MT, rX, n, nullT, nullT, 0, nullT, nullT, 0, part, wgsync);      // rH += M rX
         if (q > 0) {
-            Mat::sync(b);
             for (int j = b.tid; j < m; j += NT) {
                 T acc = rH[j];
                 for (int r = 0; r < q; ++r) acc = fma_(F[lay.W + (size_t)j * q + r], rY[r], acc);
                 rH[j] = acc;
             }
+            Mat::sync(b);
         }
-        Mat::sync(b);
         Mat::solve_neg(b, g, E, rd, m, rH, oZ, vTm, scr);
-        block_matTvec<T, 0>(b, oX, F + lay.Kneg, rX, n, n);
-        Mat::sync(b);
+        resid_cols_all<T, T>(b, NT, oX, nullT, n, F + lay.Kneg, rX, n, nullT, nullT, 0, nullT, nullT, 0, part, wgsync);  // oX = -K rX
         block_matvec16<T, 2>(b, oX, F + lay.MT, oZ, n, m);
         if (q > 0) {
             Mat::sync(b);
@@ -1533,7 +1582,7 @@ QPX_DEV void polish_mat_role(const Block& b, const PolishArgs<T>& a, int qp, T* 
             // resx = rx + Q dx + G^T dz + A^T dy;  -resz = -(ds + rz + G dx);  resy = ry + A dx
             for (int i = b.tid; i < M8; i += NT) vCZ[i] = (i < m) ? (-rS[i] - oZ[i]) * vD[i] + rZ[i] : T(0);       // ds + rz
             Mat::sync(b);
-            resid_cols<T, T>(b, vWX, rX, n, Qg, oX, n, Gg, oZ, m, Ag, oY, q);
+            resid_cols_all<T, T>(b, NT, vWX, rX, n, Qg, oX, n, Gg, oZ, m, Ag, oY, q, part, wgsync);
             resid_rows<T, T, T>(b, vRH, vCZ, nullptr, Gg, oX, m, n, -1.0);
             if (Ag) resid_rows<T, T, T>(b, vWY, rY, nullptr, Ag, oX, q, n, 1.0);
             for (int i = b.tid + m; i < M8; i += NT) vRH[i] = T(0);
@@ -1557,7 +1606,7 @@ QPX_DEV void polish_mat_role(const Block& b, const PolishArgs<T>& a, int qp, T* 
 
     for (int st = 0; st <= a.steps; ++st) {
         // ---- residuals of the current iterate (double accumulation), mu, the reference's total residual, best iterate
-        resid_cols<T, double>(b, vRX, pg, n, Qg, xd, n, Gg, zd, m, Ag, yd, q);         // Q symmetric: column-parallel over its rows
+        resid_cols_all<T, double>(b, NT, vRX, pg, n, Qg, xd, n, Gg, zd, m, Ag, yd, q, part, wgsync);         // Q symmetric: column-parallel over its rows
         resid_rows<T, double, double>(b, vRZ, sd, hg, Gg, xd, m, n, 1.0);
         if (Ag) resid_rows<T, double, double>(b, vRY, (const double*)nullptr, bg, Ag, xd, q, n, 1.0);
         Mat::sync(b);
@@ -1662,12 +1711,12 @@ QPX_DEV void polish_grid_body(const Block& b, const PolishArgs<T>& a, int qp, T*
     polish_mat_body<T, GridMat<T, GS, NBL>>(b, a, qp, lds);
 }
 
-// LDS elements (of T, tsize bytes each) of the finishing kernel: 22 vectors + 16 of T, 8 vectors + 16 scalars of double,
+// LDS elements (of T, tsize bytes each) of the finishing kernel: 22 vectors + 16 of T, 8 vectors + 16 scalars + 256 partial sums of double,
 // the matrix operations' scratch
 QPX_LAYOUT_HD size_t lds_elems_polish_mat(size_t mp, size_t scratch, int n, int q, size_t tsize)
 {
     const size_t v = align4(max2(max2((size_t)n, mp), (size_t)q));
-    return 22 * v + 16 + (8 * v + 16) * (8 / tsize) + scratch;
+    return 22 * v + 16 + (8 * v + 16 + 256) * (8 / tsize) + scratch;        // (+ 256 doubles: the partial sums of the column products)
 }
 QPX_LAYOUT_HD size_t lds_elems_polish_grid(int gs, int nbl, int n, int q, size_t tsize)
 {

@@ -654,7 +654,9 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // straight-line block -- operands loaded up front, the MFMAs of its tiles interleaved (k-slice outermost), 83
     // cycles per MFMA -- and only the row as a whole, the restart of the panel's own column and the tile the chain wave
     // has taken over sit behind (scalar) conditions.
-    // kSweep (tile sweep, qpx_tsweep.h): the symmetric sweep instead of the elimination -- EVERY tile row gets the
+    // kSweep (the round-3 pre-factorisation on matrix-core tiles, deleted in round 4 after it lost its A/B; the parameter
+    // stays false in every instantiation -- the branches below are kept because removing them from the headline kernel's
+    // source for tidiness is not worth a regression): the symmetric sweep instead of the elimination -- EVERY tile row gets the
     // update (rows above the panel accumulate the negated inverse of the swept block), the panel's own row becomes
     // (-D^-1 b_Ip)^T b_J instead of b_J.
     template <int W, int PP, bool kSweep>

@@ -224,7 +224,7 @@ a non-zero diagonal.
         return dx, ds, dz, dy
 
     # -- KKTSolvers.IR_UNOPT (batch.py:244-270) as a finishing stage --------------------------------
-    def polish(self, p, h, b, res, steps=2, refine=1):
+    def polish(self, p, h, b, res, steps=2, refine=0):
         """The finishing stage: `steps` iterations of the reference's PDIPM loop (batch.py:92-198) in the original
         variables, on residuals of the caller's data, from the loop kernel's result; the best iterate is kept.  ONE
         kernel launch (qpx_polish, include/qpx.h v6) wherever the thread-grid / tile kernels serve the size; the

@@ -154,7 +154,7 @@ def forward(Q, p, G, h, A, b, Q_LU, S_LU, R, eps=1e-12, verbose=0, notImprovedLi
     # and runs it for both.  IR_UNOPT adds what its name promises: steps on the residual of the ORIGINAL system.
     res = fac.ipm(p, h, b, eps, maxIter, notImprovedLim, stall_policy, want_trace=(verbose == 1))
     if solver == KKTSolvers.IR_UNOPT:
-        res = fac.polish(p, h, b, res)
+        res = fac.polish(p, h, b, res, refine=1)          # (its solves refined as well: solve_kkt_ir is what the name asks for)
     if verbose == 1:
         tr = res.trace.cpu()
         it_max = int(res.iters.max().item())

@@ -78,4 +78,6 @@ done
 cat $PROF/${TAG}_ab_r03.txt >> $OUT/summary.txt
 fi
 tail -5 $OUT/bench.err >> $OUT/summary.txt
+echo "== finishing kernel: time by (steps, refine)" | tee -a $OUT/summary.txt
+timeout 200 python scripts/prof_polish.py 2>&1 | grep -v amdgpu.ids | tee $PROF/${TAG}_polish_steps.txt >> $OUT/summary.txt
 du -sh $OUT | tee -a $OUT/summary.txt

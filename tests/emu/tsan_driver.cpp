@@ -66,6 +66,17 @@ int main(int argc, char** argv)
                       Q.data(), (int64_t)n * n, G.data(), (int64_t)m * n,
                       q ? A.data() : nullptr, (int64_t)q * n, status.data(), nullptr);
     if (rc) { fprintf(stderr, "backward rc %d\n", rc); return 2; }
+    // the finishing stage (qpx_polish, v6) where the kernel family has it: one step from the loop's result, one refinement
+    // step per solve; it may only improve the residual it reports
+    if (qpx_polish_supported(QPX_F64, n, m, q)) {
+        std::vector<double> z2 = zhat, nu2 = nu, lam2 = lam, sl2 = sl, br2(B);
+        rc = qpx_polish(QPX_F64, B, n, m, q, Q.data(), (int64_t)n * n, p.data(), n, G.data(), (int64_t)m * n, h.data(), m,
+                        q ? A.data() : nullptr, (int64_t)q * n, q ? bb.data() : nullptr, q, fac.data(), (int64_t)fe, 1, 1,
+                        z2.data(), q ? nu2.data() : nullptr, lam2.data(), sl2.data(), br2.data(), status.data(), nullptr);
+        if (rc) { fprintf(stderr, "polish rc %d\n", rc); return 2; }
+        for (int s = 0; s < B; ++s)
+            if (!(br2[s] == br2[s])) { fprintf(stderr, "polish: NaN residual for qp %d\n", s); return 6; }
+    }
     // the shared-parameter reduction (batch-mean of dQ as one contraction over the batch)
     std::vector<double> dQm((size_t)n * n);
     rc = qpx_batch_outer(QPX_F64, B, n, n, dx.data(), zhat.data(), zhat.data(), dx.data(), 0.5, dQm.data(), nullptr);

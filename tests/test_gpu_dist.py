@@ -104,3 +104,27 @@ def test_bench_strong_scaling_contract_under_torchrun(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["global_batch"] == 65536
     assert d["value"] > 0 and d["steps"] == 3
+
+
+def test_default_bench_line_carries_both_readings_of_the_metric_at_n_gpus(tmp_path):
+    """The DEFAULT bench.py --gpus N (what the driver runs for the scaling curve): weak C2 as `value` and, under
+    `extra.c5_strong_scaling`, the north star's fixed global batch of 65 536 over the same N ranks (round 4).  Needs >= 2
+    visible GPUs."""
+    import json
+    import subprocess
+    import sys
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("RCCL PATH NOT EXERCISED: %d GPU visible on this box (needs >= 2)" % world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "3",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True, env=env).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["global_batch"] == 512 * world
+    x = d["extra"]["c5_strong_scaling"]
+    assert x["global_batch"] == 65536 and x["n_gpus"] == world and x["scaling"] == "strong" and x["value"] > 0
