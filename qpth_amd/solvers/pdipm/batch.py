@@ -122,23 +122,32 @@ def factor_solve_kkt(Q, D, G, A, rx, rs, rz, ry):
 def factor_solve_kkt_reg(Q_tilde, D, G, A, rx, rs, rz, ry, eps):
     """factor_solve_kkt_reg (batch.py:273-310): the KKT system with -eps I in the (z, z) and (y, y) blocks,
         Q~ dx + G^T dz + A^T dy = -rx,  D ds + dz = -rs,  G dx + ds - eps dz = -rz,  A dx - eps dy = -ry.
-    Without equality constraints the regularisation is a change of the diagonal -- eliminating ds leaves
-    G dx - (1/d + eps) dz = -rz + rs/d, i.e. the un-regularised system with d' = d / (1 + eps d) and rs' = rs d'/d -- and
-    runs on the same kernels.  With equality constraints it would need A Q~^-1 A^T + eps I inside the pre-factorisation, which
-    the kernels do not offer: NotImplementedError (use solve_kkt_ir, whose refinement needs no regularisation)."""
+    The (z, z) part is a change of the diagonal -- eliminating ds leaves G dx - (1/d + eps) dz = -rz + rs/d, i.e. the
+    un-regularised system with d' = d / (1 + eps d) and rs' = rs d'/d -- and runs on the same kernels.  The (y, y) part
+    (round 4; refused until then) is a rank-neq correction of that system: its last row reads A dx = -(ry - eps dy), and
+    the solution is linear in ry, so with Y = d(dy)/d(ry) (neq solves with unit right-hand sides, independent of the
+    caller's) dy solves (I + eps Y) dy = dy0 and one more solve with ry - eps dy gives the rest: neq + 2 launches of the
+    fused factor / solve kernel and one neq x neq system per QP."""
     nineq, nz, neq, nBatch = get_sizes(G, A)
-    if neq > 0:
-        raise NotImplementedError("qpth_amd: factor_solve_kkt_reg with equality constraints (the -eps I block of dy) is "
-                                  "not built; solve_kkt_ir refines without regularisation")
     d = _diag_of(D)
     fac = _dp.KKTFactors.build(Q_tilde, G, A)
     fac.raise_on_failure()
     dreg = d / (1.0 + eps * d)
     rs_ = rs if rs is not None else torch.zeros_like(rz if rz is not None else d.expand(nBatch, nineq))
-    dx, _, dz, dy = fac.solve_kkt(dreg, rx, rs_ / (1.0 + eps * d), rz, ry)
+    rs_reg = rs_ / (1.0 + eps * d)
+    ry_eff = ry
+    if neq > 0:
+        dreg_b = dreg if dreg.dim() == 2 else dreg.unsqueeze(0).expand(nBatch, nineq)
+        ry0 = ry if ry is not None else torch.zeros(nBatch, neq, dtype=Q_tilde.dtype, device=Q_tilde.device)
+        dy0 = fac.solve_kkt(dreg_b, rx, rs_reg, rz, ry0)[3]
+        eye = torch.eye(neq, dtype=Q_tilde.dtype, device=Q_tilde.device)
+        cols = [fac.solve_kkt(dreg_b, None, None, None, eye[j].expand(nBatch, neq).contiguous())[3] for j in range(neq)]
+        Y = torch.stack(cols, dim=2)                                     # Y[:, :, j] = dy for ry = e_j
+        dy_reg = torch.linalg.solve(eye + eps * Y, dy0.unsqueeze(2)).squeeze(2)
+        ry_eff = ry0 - eps * dy_reg
+    dx, _, dz, dy = fac.solve_kkt(dreg, rx, rs_reg, rz, ry_eff)
     ds = (-rs_ - dz) / (d if d.dim() == 2 else d.unsqueeze(0))      # the second block row with the caller's d
     return dx, ds, dz, dy
-
 
 def forward(Q, p, G, h, A, b, Q_LU, S_LU, R, eps=1e-12, verbose=0, notImprovedLim=3,
             maxIter=20, solver=KKTSolvers.LU_PARTIAL, stall_policy=None):

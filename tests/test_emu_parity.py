@@ -639,38 +639,51 @@ def test_full_system_solvers_with_the_reference_signatures():
         assert np.allclose(c.numpy(), g["full_" + key], rtol=1e-8, atol=1e-9), key
 
 
-def _dense_reg_solve(Q, D, G, rx, rs, rz, eps):
-    """the regularised KKT system of batch.py:273-310 (neq = 0) solved densely in numpy"""
+def _dense_reg_solve(Q, D, G, rx, rs, rz, eps, A=None, ry=None):
+    """the regularised KKT system of batch.py:273-310 solved densely in numpy (unknowns dx, ds, dz, dy)"""
     n, m = Q.shape[0], G.shape[0]
-    K = np.zeros((n + 2 * m, n + 2 * m))
-    K[:n, :n] = Q; K[:n, n + m:] = G.T
-    K[n:n + m, n:n + m] = D; K[n:n + m, n + m:] = np.eye(m)
-    K[n + m:, :n] = G; K[n + m:, n:n + m] = np.eye(m); K[n + m:, n + m:] = -eps * np.eye(m)
-    sol = np.linalg.solve(K, -np.concatenate([rx, rs, rz]))
-    return sol[:n], sol[n:n + m], sol[n + m:]
+    q = 0 if A is None else A.shape[0]
+    K = np.zeros((n + 2 * m + q, n + 2 * m + q))
+    K[:n, :n] = Q; K[:n, n + m:n + 2 * m] = G.T
+    K[n:n + m, n:n + m] = D; K[n:n + m, n + m:n + 2 * m] = np.eye(m)
+    K[n + m:n + 2 * m, :n] = G; K[n + m:n + 2 * m, n:n + m] = np.eye(m); K[n + m:n + 2 * m, n + m:n + 2 * m] = -eps * np.eye(m)
+    rhs = [rx, rs, rz]
+    if q:
+        K[:n, n + 2 * m:] = A.T; K[n + 2 * m:, :n] = A; K[n + 2 * m:, n + 2 * m:] = -eps * np.eye(q)
+        rhs.append(ry)
+    sol = np.linalg.solve(K, -np.concatenate(rhs))
+    return sol[:n], sol[n:n + m], sol[n + m:n + 2 * m], sol[n + 2 * m:]
 
 
-def test_regularised_full_solve():
-    """factor_solve_kkt_reg (batch.py:273-310): without equality constraints the -eps I block is a change of d; with
-    them it is refused by name."""
+@pytest.mark.parametrize("q", [0, 4])
+def test_regularised_full_solve(q):
+    """factor_solve_kkt_reg (batch.py:273-310) against a dense solve of the same regularised system: without equality
+    constraints the -eps I block is a change of d; with them (round 4) a rank-neq correction on top (neq + 2 launches)."""
     B, n, m = 3, 12, 9
-    Q, p, G, h, A, b = problems.prof_qp(B, n, m, 0, seed=4)
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed=4)
     r = np.random.RandomState(2)
     d = r.rand(B, m) + 0.1
-    rx, rs, rz = r.randn(B, n), r.randn(B, m), r.randn(B, m)
+    rx, rs, rz, ry = r.randn(B, n), r.randn(B, m), r.randn(B, m), r.randn(B, q)
     eps = 1e-3
-    e = torch.empty(0, dtype=torch.float64)
+    tA = torch.tensor(A) if q else torch.empty(0, dtype=torch.float64)
     with emulated():
-        dx, ds, dz, dy = pdipm_b.factor_solve_kkt_reg(torch.tensor(Q), torch.diag_embed(torch.tensor(d)), torch.tensor(G), e,
-                                                      torch.tensor(rx), torch.tensor(rs), torch.tensor(rz), None, eps)
-    assert dy is None
+        dx, ds, dz, dy = pdipm_b.factor_solve_kkt_reg(torch.tensor(Q), torch.diag_embed(torch.tensor(d)), torch.tensor(G), tA,
+                                                      torch.tensor(rx), torch.tensor(rs), torch.tensor(rz),
+                                                      torch.tensor(ry) if q else None, eps)
+    assert (dy is None) == (q == 0)
     for i in range(B):
-        ex, es, ez = _dense_reg_solve(Q[i], np.diag(d[i]), G[i], rx[i], rs[i], rz[i], eps)
-        for mine, ref in ((dx[i], ex), (ds[i], es), (dz[i], ez)):
+        ex, es, ez, ey = _dense_reg_solve(Q[i], np.diag(d[i]), G[i], rx[i], rs[i], rz[i], eps, A[i] if q else None, ry[i] if q else None)
+        pairs = [(dx[i], ex), (ds[i], es), (dz[i], ez)] + ([(dy[i], ey)] if q else [])
+        for mine, ref in pairs:
             assert np.abs(mine.numpy() - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+    # the reference's own use of it (solve_kkt_ir: eps = 1e-7) on its KKT test problem (test.py:190-219): within 1e-6 of
+    # the un-regularised solution the golden file holds
     g, Qe, Gg, Ae, dd, rxx, rss, rzz, ryy = _kkt_solver_golden()
-    with pytest.raises(NotImplementedError, match="equality"):
-        pdipm_b.factor_solve_kkt_reg(Qe, torch.diag_embed(dd), Gg, Ae, rxx, rss, rzz, ryy, 1e-7)
+    with emulated():
+        outs = pdipm_b.factor_solve_kkt_reg(Qe + 1e-7 * torch.eye(5, dtype=torch.float64), torch.diag_embed(dd) + 1e-7 * torch.eye(4, dtype=torch.float64),
+                                            Gg, Ae, rxx, rss, rzz, ryy, 1e-7)
+    for mine, key in zip(outs, ("dx", "ds", "dz", "dy")):
+        assert np.allclose(mine.numpy(), g["full_" + key], rtol=1e-5, atol=1e-5), key
 
 
 def test_refinement_is_refused_loudly_where_no_kernel_implements_it():

@@ -123,8 +123,11 @@ def test_solve_kkt_ir_and_full_solvers_match_the_reference(dev):
         for mine, key in zip(o, ("dx", "ds", "dz", "dy")):
             assert np.allclose(mine.cpu().numpy(), g["full_" + key], rtol=1e-8, atol=1e-9), (name, key)
             assert np.allclose(mine.cpu().numpy(), g[key], rtol=1e-8, atol=1e-9), (name, key)
-    with pytest.raises(NotImplementedError, match="equality"):
-        pdipm_b.factor_solve_kkt_reg(Qe, D, G, Ae, rx, rs, rz, ry, 1e-7)
+    # the regularised solve with equality constraints (round 4), as the reference's solve_kkt_ir uses it (eps = 1e-7):
+    # within 1e-5 of the un-regularised golden solution
+    e5, e4 = torch.eye(5, dtype=torch.float64, device=dev), torch.eye(4, dtype=torch.float64, device=dev)
+    for mine, key in zip(pdipm_b.factor_solve_kkt_reg(Qe + 1e-7 * e5, D + 1e-7 * e4, G, Ae, rx, rs, rz, ry, 1e-7), ("dx", "ds", "dz", "dy")):
+        assert np.allclose(mine.cpu().numpy(), g["full_" + key], rtol=1e-5, atol=1e-5), key
     # regularised solve without equality constraints against a dense numpy solve of the same system
     B, n, m, eps = 4, 100, 100, 1e-3
     Qn, pn, Gn, hn, An, bn = problems.prof_qp(B, n, m, 0, seed=4)
