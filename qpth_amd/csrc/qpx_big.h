@@ -414,18 +414,24 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
     T* C = Cq + big_blk(a.ldc, crb, ccb);                                      // this tile: 4096 consecutive elements
     const T* Cs = a.Cs ? a.Cs + (size_t)qp * a.sCs + big_blk(a.ldcs, crb, ccb) : C;
     T cs[2][2][4];
-    if (!a.zero_init) {
+    auto load_c = [&]() {
+        if (!a.zero_init) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
+                for (int y = 0; y < 2; ++y)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    cs[x][y][r] = Cs[(qr + 16 * x + Block::mfma_row(T(0), g, r)) * kBB + qc + 16 * y + c16];
-    }
+                    for (int r = 0; r < 4; ++r)
+                        cs[x][y][r] = Cs[(qr + 16 * x + Block::mfma_row(T(0), g, r)) * kBB + qc + 16 * y + c16];
+        }
+    };
+    load_c();
     // staging coordinates: A (and B as [column][k]): row sr, k 4 sq ..; B as [k][column]: k-row tr, columns 4 tq ..
     const int sr = b.tid >> 2, sq = b.tid & 3, tr = b.tid >> 4, tq = b.tid & 15;
     const int nch = a.nk * (kBB / kGC);
+    // (one chunk of operands in flight per thread.  Two measured 5 % SLOWER at C4 with the C tile still fetched up front
+    // -- four spilled registers at the 128-register limit of four workgroups per CU -- and EQUAL with the C tile fetched
+    // after the k-loop instead (114 registers, no spill): the launches are not waiting for their operands.  profiles/r04j, r04k.)
     T pa[4], pb[4];
     auto fetch = [&](int ch) {
         const int kb = ch >> 2, ko = (ch & 3) * kGC;                           // k-block, offset of the chunk inside it
@@ -545,7 +551,7 @@ template <class T, int NW> QPX_DEV void big_trsv_body(const Block& b, const BigT
         for (int u = 0; u < kBB / NW; ++u) wv[u] = Wg[(w + NW * u) * kBB];
         {
             // rows c of the stored matrix (L^T above the diagonal for dir 0, L below it for dir 1), element k0 + lane;
-            // eight independent loads in flight per lane
+            // eight independent loads in flight per lane (sixteen measured no better: profiles/r04j)
             // (row c of block column k: block (c / 64, k), its row c % 64 -- consecutive rows are consecutive memory)
             auto at = [&](int c) { return M[big_blk(a.ld, c >> 6, k) + (size_t)(c & 63) * kBB + lane]; };
             T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
@@ -595,6 +601,11 @@ template <class T> struct BigGemvArgs {
     T alpha, beta;
     const int* ctrl; size_t sctrl; int check_stop;
 };
+// LDS: the vector x (up to 512 elements) + 4 x 64 partial sums
+QPX_LAYOUT_HD size_t big_gemv_lds_elems() { return (size_t)8 * kBB + 4 * kWave; }
+#ifndef QPX_BIG_GEMV_ROWS
+#define QPX_BIG_GEMV_ROWS 4          // rows a wave works on at once (x two column blocks: loads in flight per lane)
+#endif
 template <class T> QPX_DEV void big_gemv_body(const Block& b, const BigGemvArgs<T>& a, int qp, int chunk, T* lds)
 {
     if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
@@ -603,27 +614,72 @@ template <class T> QPX_DEV void big_gemv_body(const Block& b, const BigGemvArgs<
     const T* y0 = a.y0 ? a.y0 + (size_t)qp * a.sy0 : nullptr;
     T* y = a.y + (size_t)qp * a.sy;
     const int lane = b.lane(), w = b.uniform(b.wave()), nw = b.nwaves();
+    // (round 4) The first form walked a row with ONE matrix load in flight per lane (the compiler waits for each load
+    // of the run-time column loop before the next: `s_waitcnt vmcnt(0)` per iteration) and fetched x from global memory
+    // beside it -- 3.7 TB/s on a part whose plain streaming read reaches 5.7 (scripts/bw_probe.py).  Now x sits in LDS
+    // and a wave keeps RB rows x 2 column blocks = eight independent loads in flight.
+    T* xl = lds;                                 // x, padded with zeros to whole blocks of 64
+    T* part = lds + 8 * kBB;
+    const int nx = a.trans ? a.rows : a.cols, nxp = (nx + kBB - 1) / kBB * kBB;
+    for (int i = b.tid; i < nxp; i += b.nt) xl[i] = i < nx ? x[i] : T(0);
+    b.sync();
     if (!a.trans) {
-        for (int r = w; r < kBB; r += nw) {
-            const int i = chunk * kBB + r;
-            if (i >= a.rows) break;
-            const T* row = M + big_blk(a.ld, i >> 6, 0) + (size_t)(i & 63) * kBB + lane;      // + a block per 64 columns
-            T acc = T(0);
-            for (int c = lane, cb = 0; c < a.cols; c += kWave, ++cb) acc = fma_(row[(size_t)cb * kBE], x[c], acc);
-            acc = wave_sum(b, acc);
-            if (lane == 0) y[i] = fma_(a.alpha, acc, y0 ? a.beta * y0[i] : T(0));
+        constexpr int RB = QPX_BIG_GEMV_ROWS;
+        const int ncb = nxp / kBB;
+        for (int r0 = w * RB; r0 < kBB; r0 += nw * RB) {
+            const int i0 = chunk * kBB + r0;
+            if (i0 >= a.rows) break;
+            // rows i0 .. i0 + RB - 1 of block row `chunk` (the padded rows of the blob exist: loads stay unconditional)
+            const T* row = M + big_blk(a.ld, chunk, 0) + (size_t)r0 * kBB + lane;
+            T acc[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) acc[u] = T(0);
+            int cb = 0;
+            for (; cb + 2 <= ncb; cb += 2) {
+                T m0[RB], m1[RB];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) { m0[u] = row[(size_t)cb * kBE + u * kBB]; m1[u] = row[(size_t)(cb + 1) * kBE + u * kBB]; }
+                const T x0 = xl[cb * kBB + lane], x1 = xl[(cb + 1) * kBB + lane];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) acc[u] = fma_(m1[u], x1, fma_(m0[u], x0, acc[u]));
+            }
+            if (cb < ncb) {
+                const T x0 = xl[cb * kBB + lane];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) acc[u] = fma_(row[(size_t)cb * kBE + u * kBB], x0, acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) acc[u] = wave_sum(b, acc[u]);
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < RB; ++u)
+                    if (i0 + u < a.rows) y[i0 + u] = fma_(a.alpha, acc[u], y0 ? a.beta * y0[i0 + u] : T(0));
+            }
         }
     } else {
-        // 64 output columns, the rows dealt over the four waves, partial sums combined through LDS
+        // 64 output columns, the rows dealt over the four waves (eight in flight per lane), partial sums combined through LDS
         const int j = chunk * kBB + lane;
-        T acc = T(0);
-        if (j < a.cols)
-            for (int i = w; i < a.rows; i += nw) acc = fma_(M[big_blk(a.ld, i >> 6, chunk) + (size_t)(i & 63) * kBB + lane], x[i], acc);
-        lds[w * kWave + lane] = acc;
+        T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+        auto at = [&](int i) { return M[big_blk(a.ld, i >> 6, chunk) + (size_t)(i & 63) * kBB + lane]; };
+        int i = w;
+        for (; i + 7 * nw < nxp; i += 8 * nw) {
+            const T m0 = at(i), m1 = at(i + nw), m2 = at(i + 2 * nw), m3 = at(i + 3 * nw);
+            const T m4 = at(i + 4 * nw), m5 = at(i + 5 * nw), m6 = at(i + 6 * nw), m7 = at(i + 7 * nw);
+            a0 = fma_(m0, xl[i], a0);
+            a1 = fma_(m1, xl[i + nw], a1);
+            a2 = fma_(m2, xl[i + 2 * nw], a2);
+            a3 = fma_(m3, xl[i + 3 * nw], a3);
+            a4 = fma_(m4, xl[i + 4 * nw], a4);
+            a5 = fma_(m5, xl[i + 5 * nw], a5);
+            a6 = fma_(m6, xl[i + 6 * nw], a6);
+            a7 = fma_(m7, xl[i + 7 * nw], a7);
+        }
+        for (; i < nxp; i += nw) a0 = fma_(at(i), xl[i], a0);
+        part[w * kWave + lane] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
         b.sync();
         if (w == 0 && j < a.cols) {
             T s = T(0);
-            for (int ww = 0; ww < nw; ++ww) s += lds[ww * kWave + lane];
+            for (int ww = 0; ww < nw; ++ww) s += part[ww * kWave + lane];
             y[j] = fma_(a.alpha, s, y0 ? a.beta * y0[j] : T(0));
         }
     }

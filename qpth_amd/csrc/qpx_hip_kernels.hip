@@ -383,7 +383,7 @@ template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* s)
 {
     static BigLdsFlags f;
     const int outs = a.trans ? a.cols : a.rows;
-    return big_launch(k_big_gemv<T>, a, a.B, (outs + kBB - 1) / kBB, 256, 4 * kWave * sizeof(T), s, f);
+    return big_launch(k_big_gemv<T>, a, a.B, (outs + kBB - 1) / kBB, 256, big_gemv_lds_elems() * sizeof(T), s, f);
 }
 template <class T> int launch_big_vec(const BigVecArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_vec<T>, a, a.B, 1, 256, 0, s, f); }
 template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* s) { static BigLdsFlags f; return big_launch(k_big_kkt<T>, a, a.B, gy, 256, 0, s, f); }

@@ -389,7 +389,7 @@ template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void*)
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void*)
 {
     const int outs = a.trans ? a.cols : a.rows;
-    big_grid(a.B, (outs + kBB - 1) / kBB, 256, 4 * kWave * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemv_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
+    big_grid(a.B, (outs + kBB - 1) / kBB, 256, big_gemv_lds_elems() * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemv_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
     return QPX_OK;
 }
 template <class T> int launch_big_vec(const BigVecArgs<T>& a, void*)
