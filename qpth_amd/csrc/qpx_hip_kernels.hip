@@ -8,7 +8,7 @@
 // 3 = kkt/backward, 5 = sweep pre-factorisation (16x16 thread grid),
 // 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only),
 // 10 = batch-mean outer products of shared-parameter gradients, 11 = the large-QP family (qpx_big.h),
-// 13 = the finishing stage on matrix-core tiles (f64 only; its thread-grid form lives in 7).  (12 was the sweep
+// 13 = the finishing stage on matrix-core tiles (f64 only; its thread-grid form lives in 7), 14 = pre_factor_kkt on matrix-core tiles (f64 only).  (12 was the sweep
 // pre-factorisation on matrix-core tiles of round 3: parity-green, never faster than the thread-grid sweep, deleted in round 4.)
 #include <hip/hip_runtime.h>
 
@@ -206,6 +206,24 @@ template <int NBL, int NW, bool CH> int launch_polish_tile(const PolishArgs<doub
 }
 #define QPX_INSTPT(NBL, NW, CH) template int launch_polish_tile<NBL, NW, CH>(const PolishArgs<double>&, size_t, void*);
 QPX_INSTPT(1, 1, false) QPX_INSTPT(2, 1, false) QPX_INSTPT(4, 1, false) QPX_INSTPT(4, 4, true) QPX_INSTPT(7, 4, true)
+#elif QPX_TU_KERNEL == 14
+// pre_factor_kkt on matrix-core tiles (qpx_prefac.h), f64, neq = 0: four waves per QP, two QPs per CU
+template <int NBN> __global__ __launch_bounds__(256, 2) void k_prefac_tile(PrefactorArgs<double> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    prefac_tile_body<NBN>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+}
+template <int NBN> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_prefac_tile<NBN>;
+    static BigLdsFlags big_lds_enabled;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+template int launch_prefac_tile<4>(const PrefactorArgs<double>&, size_t, void*);
+template int launch_prefac_tile<7>(const PrefactorArgs<double>&, size_t, void*);
 #elif QPX_TU_KERNEL == 10 || QPX_TU_KERNEL == 11
 // defined below, outside the launcher chain
 #elif QPX_TU_KERNEL == 9

@@ -312,6 +312,9 @@ template <class T> struct PrefactorArgs {
     int* status;
     int images;                           // blob family / register images of R (qpx_layout.h: fac_layout)
     int io32 = 0;                         // T = double only: Q, G, A are float32 arrays (QPX_F32_WIDE)
+    // matrix-core form (qpx_prefac.h) only: which tiles of K (pf_k) and of R (pf_r) each of the four waves computes, bit
+    // t = tile (i, j), t = i (i + 1) / 2 + j -- a greedy balance the host works out once per launch (prefac_deal)
+    unsigned pf_k[4] = {0, 0, 0, 0}, pf_r[4] = {0, 0, 0, 0};
 };
 
 template <class T> struct IpmArgs {

@@ -250,6 +250,45 @@ template <> QPX_DEV double GlobalRows<double>::row(int r) const
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, r * kWave * 8, 0));
 }
 
+// Elements of a wave-uniform global array addressed by (per-lane element offset) + (wave-uniform element offset) + (compile-
+// time element offset), widened to double: buffer loads, so that many loads share ONE 32-bit lane-offset register and the
+// rest of the address lives in scalar registers / the instruction (a kernel that gathers ~40 elements per lane with
+// global_load keeps ~40 64-bit addresses alive).  An offset at or beyond `nelem` reads as ZERO (the range check of a raw
+// buffer: byte offset + size > num_records), which the callers use for rows of padding; offsets are never negative.
+template <class S> struct GlobalBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    QPX_DEV GlobalBuf(const S* base, long long nelem)
+    {
+        const unsigned long long p = (unsigned long long)base;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(p & 0xffffffffull));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        void* up = (void*)(((unsigned long long)hi << 32) | lo);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(up, 0, (int)(nelem * (long long)sizeof(S)), 0x00020000);
+    }
+    QPX_DEV double at(int off) const;
+    QPX_DEV void at2(int off, double (&v)[2]) const;      // elements off, off + 1: one access
+};
+template <> QPX_DEV double GlobalBuf<float>::at(int off) const
+{
+    return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off * 4, 0, 0));
+}
+template <> QPX_DEV double GlobalBuf<double>::at(int off) const
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off * 8, 0, 0));
+}
+template <> QPX_DEV void GlobalBuf<float>::at2(int off, double (&v)[2]) const
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 x = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off * 4, 0, 0));
+    v[0] = (double)x[0]; v[1] = (double)x[1];
+}
+template <> QPX_DEV void GlobalBuf<double>::at2(int off, double (&v)[2]) const
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 x = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off * 8, 0, 0));
+    v[0] = x[0]; v[1] = x[1];
+}
+
 // four consecutive elements at a 4-element-aligned address: one 128-bit access (float) or two (double)
 template <class T> QPX_DEV void ld4(const T* p, T (&v)[4])
 {

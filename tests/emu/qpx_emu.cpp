@@ -17,6 +17,7 @@
 #include "qpx_kernels.h"
 #include "qpx_grid.h"
 #include "qpx_tile.h"
+#include "qpx_prefac.h"
 #include "qpx_reduce.h"
 #include "qpx_big.h"
 
@@ -285,6 +286,15 @@ template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t l
         std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         T* base = reinterpret_cast<T*>(lds.data());
         run_block(256, [&](const Block& b) { sweep_body<T, NBL>(b, a, qp, base); });
+    }
+    return QPX_OK;
+}
+template <int NBN> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
+        double* base = reinterpret_cast<double*>(lds.data());
+        run_block(256, [&](const Block& b) { prefac_tile_body<NBN>(b, a, qp, base); });
     }
     return QPX_OK;
 }

@@ -17,6 +17,8 @@
 #include <pthread.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -201,6 +203,18 @@ template <class T> struct GlobalRows {
     int lane;
     GlobalRows(const T* b, int /*nelem*/, int l) : base(b), lane(l) {}
     T row(int r) const { return base[(size_t)r * kWave + lane]; }
+};
+
+template <class S> struct GlobalBuf {
+    const S* base;
+    long long nelem;
+    GlobalBuf(const S* b, long long ne) : base(b), nelem(ne) {}
+    double at(int off) const          // at or beyond nelem: zero (the raw buffer's range check); negative: a bug
+    {
+        if (off < 0) { std::fprintf(stderr, "GlobalBuf: negative offset %d\n", off); std::abort(); }
+        return off >= nelem ? 0.0 : (double)base[off];
+    }
+    void at2(int off, double (&v)[2]) const { v[0] = at(off); v[1] = at(off + 1); }
 };
 
 template <class T> inline void ld4(const T* p, T (&v)[4]) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }

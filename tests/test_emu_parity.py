@@ -179,6 +179,76 @@ def test_sweep_by_groups_of_four_reports_breakdowns(shape):
             QPFunction(verbose=-1)(Q, p, G, h, Ab, bb)
 
 
+def _grid_blob_regions(n, m):
+    """sub-arrays of the family-(a) blob at neq = 0 with the tile image only (qpx_layout.h: fac_layout(n, m, 0, 4))"""
+    al = lambda x: (x + 3) & ~3
+    nbt = [t for t in (1, 2, 4, 7) if (m + 15) // 16 <= t][0]
+    o = al(n * n) + al(n * m)
+    return {"Kneg": (0, n * n), "MT": (al(n * n), n * m), "gt1": (o, 1), "Rm": (o + 12, nbt * (nbt + 1) // 2 * 256)}
+
+
+PREFAC_SWEEP = 1 << 14      # include/qpx.h, qpx_set_ipm_variant: pre_factor_kkt by the thread-grid sweep
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("shape", [(2, 100, 100), (1, 70, 50), (1, 64, 64), (1, 50, 112), (1, 112, 3), (1, 81, 17), (1, 97, 111), (1, 49, 1)])
+def test_matrix_core_prefactorisation_writes_the_sweeps_blob(shape, wide):
+    """Round 4: pre_factor_kkt (batch.py:375-429) at neq = 0, 49 <= nz <= 112 is a factorisation of Q + tile products on
+    the matrix cores (qpx_prefac.h) instead of the symmetric sweep.  Same blob, array by array: -K, M^T, || G^T 1 || and
+    the tile image of R (padding included: exact zeros in both); float32 tensors in float64 arithmetic too."""
+    from qpth_amd import kkt as _dp
+    B, n, m = shape
+    rng = np.random.default_rng(n * 1000 + m)
+    L = rng.standard_normal((B, n, n))
+    dt = torch.float32 if wide else torch.float64
+    Q = torch.tensor(L @ L.transpose(0, 2, 1) + 1e-2 * np.eye(n), dtype=dt)
+    G = torch.tensor(rng.standard_normal((B, m, n)), dtype=dt)
+    e = torch.empty(0, dtype=dt)
+    blobs = []
+    for variant in (0, PREFAC_SWEEP):
+        with emulated(256, variant):
+            fac = _dp.KKTFactors.build(Q, G, e, wide=wide)
+            fac.raise_on_failure()
+            blobs.append(fac.blob.reshape(B, -1).clone())
+    assert blobs[0].dtype == torch.float64 and blobs[0].shape == blobs[1].shape
+    for name, (o, ln) in _grid_blob_regions(n, m).items():
+        mine, ref = blobs[0][:, o:o + ln].numpy(), blobs[1][:, o:o + ln].numpy()
+        assert np.abs(mine - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), name
+        if name == "Rm":
+            assert ((ref == 0) == (mine == 0)).all()          # the padding of the image
+
+
+def test_matrix_core_prefactorisation_reports_a_q_that_is_not_spd():
+    """... and a pivot of Q that is not positive raises what the sweep raises (batch.py:382-386), for the QP it belongs to
+    only: the healthy QP of the batch still solves when the broken one is taken out."""
+    Q, p, G, h, A, b = [torch.tensor(x) for x in problems.prof_qp(2, 100, 50, 0, seed=3)]
+    with emulated(256):
+        Qb = Q.clone()
+        Qb[1] = -Qb[1]
+        with pytest.raises(RuntimeError, match="Cannot perform LU factorization on Q"):
+            QPFunction(verbose=-1, check_Q_spd=False)(Qb, p, G, h, A, b)
+        Qc = Q.clone()
+        Qc[0, 70, 70] = -1.0                       # breaks down in the fifth panel
+        with pytest.raises(RuntimeError, match="Cannot perform LU factorization on Q"):
+            QPFunction(verbose=-1, check_Q_spd=False)(Qc, p, G, h, A, b)
+        z = QPFunction(verbose=-1)(Q, p, G, h, A, b)
+        with emulated(256, PREFAC_SWEEP):
+            zs = QPFunction(verbose=-1)(Q, p, G, h, A, b)
+    assert rel_err(z.numpy(), zs.numpy()).max() < 1e-9
+
+
+def test_prefactorisation_knob_round_trips():
+    """bit 14 of the A/B knob selects the sweep where the matrix-core form would run; it is part of the value
+    qpx_get_ipm_variant returns (KKTFactors re-applies it around later calls on the factors)."""
+    from emu.harness import emu_lib
+    lib = emu_lib()
+    old = lib.dll.qpx_set_ipm_variant(PREFAC_SWEEP | 1024)
+    try:
+        assert lib.dll.qpx_get_ipm_variant() == (PREFAC_SWEEP | 1024)
+    finally:
+        lib.dll.qpx_set_ipm_variant(old)
+
+
 def test_verbose_trace_and_inaccuracy_warning():
     g = load_golden("c1_b8_n10_m5_f64")
     tq = tens([g[k] for k in ("Q", "p", "G", "h", "A", "b")], grad=False)

@@ -775,6 +775,61 @@ def test_every_loop_kernel_form(dev, variant, shape):
             assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
+PREFAC_SWEEP = 1 << 14      # include/qpx.h, qpx_set_ipm_variant: pre_factor_kkt by the thread-grid sweep
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("shape", [(512, 100, 100), (64, 64, 64), (33, 112, 96), (16, 70, 50), (8, 49, 112), (1024, 100, 10)])
+def test_matrix_core_prefactorisation_against_the_sweep(dev, shape, wide):
+    """Round 4: pre_factor_kkt (batch.py:375-429) on the matrix cores (qpx_prefac.h; neq = 0, 49 <= nz <= 112) writes the
+    blob the symmetric sweep writes -- -K, M^T, || G^T 1 ||, the tile image of R with its zero padding -- at C2's full
+    size and at the sizes that exercise its padding paths; float32 tensors in float64 arithmetic too."""
+    from qpth_amd import _lib
+    from qpth_amd import kkt as _dp
+    B, n, m = shape
+    rng = np.random.default_rng(n * 1000 + m)
+    L = rng.standard_normal((B, n, n))
+    dt = torch.float32 if wide else torch.float64
+    Q = torch.tensor(L @ L.transpose(0, 2, 1) + 1e-2 * np.eye(n), dtype=dt, device=dev)
+    G = torch.tensor(rng.standard_normal((B, m, n)), dtype=dt, device=dev)
+    e = torch.empty(0, dtype=dt, device=dev)
+    blobs = []
+    for variant in (0, PREFAC_SWEEP):
+        old = _lib.hip().dll.qpx_set_ipm_variant(variant)
+        try:
+            fac = _dp.KKTFactors.build(Q, G, e, wide=wide)
+            fac.raise_on_failure()
+            blobs.append(fac.blob.reshape(B, -1).cpu().numpy().copy())
+        finally:
+            _lib.hip().dll.qpx_set_ipm_variant(old)
+    al = lambda x: (x + 3) & ~3
+    nbt = [t for t in (1, 2, 4, 7) if (m + 15) // 16 <= t][0]
+    o = al(n * n) + al(n * m)
+    regions = {"Kneg": (0, n * n), "MT": (al(n * n), n * m), "gt1": (o, 1), "Rm": (o + 12, nbt * (nbt + 1) // 2 * 256)}
+    for name, (off, ln) in regions.items():
+        mine, ref = blobs[0][:, off:off + ln], blobs[1][:, off:off + ln]
+        assert np.abs(mine - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), name
+        if name == "Rm":
+            assert ((ref == 0) == (mine == 0)).all()
+    # K against numpy
+    K = -blobs[0][:, :n * n].reshape(B, n, n)
+    Kr = np.linalg.inv(Q.double().cpu().numpy())
+    assert np.abs(K - Kr).max() <= 1e-8 * np.abs(Kr).max()
+
+
+def test_matrix_core_prefactorisation_reports_a_q_that_is_not_spd(dev):
+    """a pivot that is not positive in any panel of the factorisation raises what the sweep raises (batch.py:382-386)"""
+    from qpth_amd.qp import QPFunction
+    Q, p, G, h, A, b = to_dev(problems.prof_qp(64, 100, 50, 0, seed=3), dev, grad=False)
+    for row in (0, 37, 99):
+        Qb = Q.clone()
+        Qb[5, row, row] = -1.0
+        with pytest.raises(RuntimeError, match="Cannot perform LU factorization on Q"):
+            QPFunction(verbose=-1, check_Q_spd=False)(Qb, p, G, h, A, b)
+    z = QPFunction(verbose=-1)(Q, p, G, h, A, b)
+    assert torch.isfinite(z).all()
+
+
 # ---------------------------------------------------------------- 5. the bench contract
 def test_full_size_c2_second_seed(dev):
     """C2 at its full size, a second seed and a random dl_dz: every QP and every gradient against the oracle (the
