@@ -81,3 +81,11 @@ tail -5 $OUT/bench.err >> $OUT/summary.txt
 echo "== finishing kernel: time by (steps, refine)" | tee -a $OUT/summary.txt
 timeout 200 python scripts/prof_polish.py 2>&1 | grep -v amdgpu.ids | tee $PROF/${TAG}_polish_steps.txt >> $OUT/summary.txt
 du -sh $OUT | tee -a $OUT/summary.txt
+echo "== pre-factorisation: matrix cores (default) against the sweep (knob bit 14), phases of the default" | tee -a $OUT/summary.txt
+for dims in "512 100 100 0" "2048 100 100 0" "512 64 64 0" "65536 64 64 0"; do
+  echo "-- B n m q = $dims" >> $PROF/${TAG}_ab_prefac.txt
+  timeout 300 python scripts/ab_bench.py qpth_amd/libqpx_hip.so:16384 qpth_amd/libqpx_hip.so:0 $dims 2>&1 | grep -v amdgpu.ids | tail -4 >> $PROF/${TAG}_ab_prefac.txt
+done
+[ -f qpth_amd/libqpx_hip_prof.so ] && timeout 200 python scripts/prof_prefac.py 2>&1 | grep -v amdgpu.ids >> $PROF/${TAG}_ab_prefac.txt
+cat $PROF/${TAG}_ab_prefac.txt >> $OUT/summary.txt
+du -sh $OUT | tee -a $OUT/summary.txt
