@@ -395,7 +395,7 @@ QPX_DEV void block_matvec16(const Block& blk, T* out, const T* Mat, const T* vec
 // Two column-parallel products with one vector at once: outA[c] (opA)= sum_r MatA[r][c] vec[r] (c < colsA) and
 // outB[c] (opB)= sum_r MatB[r][c] vec[r] (c < colsB): the columns of both matrices are dealt over ALL threads (one
 // product alone keeps 100 of 256 threads busy at C2) and sixteen loads are in flight per thread.
-template <class T, int MODEA, int MODEB, class Acc = T>
+template <class T, int MODEA, int MODEB, class Acc = T, int D = 16 /* loads in flight per thread */>
 QPX_DEV void block_matTvec2(const Block& blk, T* outA, const T* MatA, int colsA, T* outB, const T* MatB, int colsB,
                             const T* vec, int rows)
 {
@@ -405,20 +405,20 @@ QPX_DEV void block_matTvec2(const Block& blk, T* outA, const T* MatA, int colsA,
         const int c = isA ? cc : cc - colsAP, cols = isA ? colsA : colsB;
         if (isA && c >= colsA) continue;
         const T* col = (isA ? MatA : MatB) + c;
-        Acc a[16];
+        Acc a[D];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a[u] = Acc(0);
-        int r = 0;
-        for (; r + 16 <= rows; r += 16) {
-            T mv[16];
+        for (int u = 0; u < D; ++u) a[u] = Acc(0);
+        // (the last, partial batch too is sixteen unconditional loads -- of the last row again, times zero: a tail loop
+        // of single loads was four more round trips to memory at rows = 100)
+        for (int r = 0; r < rows; r += D) {
+            T mv[D];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) mv[u] = col[(size_t)(r + u) * cols];
+            for (int u = 0; u < D; ++u) mv[u] = col[(size_t)(r + u < rows ? r + u : rows - 1) * cols];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a[u] = fma_((Acc)mv[u], (Acc)vec[r + u], a[u]);
+            for (int u = 0; u < D; ++u) a[u] = fma_((Acc)mv[u], r + u < rows ? (Acc)vec[r + u] : Acc(0), a[u]);
         }
-        for (; r < rows; ++r) a[0] = fma_((Acc)col[(size_t)r * cols], (Acc)vec[r], a[0]);
-        const Acc sum = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
-                        (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+        Acc sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        if constexpr (D == 16) sum += ((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15]));
         T* o = (isA ? outA : outB) + c;
         const int mode = isA ? MODEA : MODEB;
         *o = mode == 0 ? (T)sum : (mode == 1 ? (T)((Acc)*o + sum) : (T)((Acc)*o - sum));
@@ -1209,16 +1209,16 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
         vRH[i] = rhs;
     }
     Mat::sync(b);
-    typename Mat::Regs E;
-    Mat::load(b, g, E, Mat::image(F, lay));
-    Mat::add_diag(g, E, vD);
-    const bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
-    if (!ok && b.tid == 0 && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
-
-    // One application of the condensed KKT inverse with the factor in E: inputs rX (n), rY (q) and rH = rs/d - rz (M8),
+    // One application of the condensed KKT inverse: inputs rX (n), rY (q) and rH = rs/d - rz (M8),
     //   oZ = -T^-1 (rH + M rX + W rY),  oX = -K rX - M^T oZ - N rY,  oY = S11^-1 rY - N^T rX - W^T oZ   (rH is overwritten)
-    auto apply = [&](const T* rX, const T* rY, T* rH, T* oZ, T* oX, T* oY) {
-        block_matTvec<T, 1>(b, rH, F + lay.MT, rX, n, m);
+    // in two halves: the products with rX, which need no factor, and the rest.  (r4) Both products at once -- rH += M rX
+    // and oX = -K rX, sixteen rows in flight per thread, all threads busy; one after the other with eight in flight they
+    // were round trips to memory one behind the other, and -K rX waited for a solve it does not need -- and, the first
+    // time, BEFORE the matrix is loaded: beside the tiles their 64 registers cost a workgroup per CU at four tile rows.
+    auto products = [&](const T* rX, const T* rY, T* rH, T* oX) {
+        // (eight in flight at up to four tile rows: sixteen made the kernel's register peak there, 142 -> 178, and cost
+        // the third workgroup per CU -- +1.4 % on the step at B = 8192, nz = nineq = 64, profiles/r04t)
+        block_matTvec2<T, 1, 0, T, (M8 > 64 ? 16 : 8)>(b, rH, F + lay.MT, m, oX, F + lay.Kneg, n, rX, n);
         if (q > 0) {
             Mat::sync(b);
             for (int j = b.tid; j < m; j += NT) {
@@ -1228,14 +1228,20 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
             }
         }
         Mat::sync(b);
+    };
+    products(vRX, vRY, vRH, vDX);
+    typename Mat::Regs E;
+    Mat::load(b, g, E, Mat::image(F, lay));
+    Mat::add_diag(g, E, vD);
+    const bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
+    if (!ok && b.tid == 0 && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
+    auto finish = [&](const T* rX, const T* rY, T* rH, T* oZ, T* oX, T* oY) {
         if (ok) Mat::solve_neg(b, g, E, rd, m, rH, oZ, vTm, scr);
         else {
             for (int i = b.tid; i < M8; i += NT) oZ[i] = T(0);
             Mat::sync(b);
         }
-        // oX = Kneg rX - M^T oZ + NTn^T rY     (Kneg = -K, NTn = -N^T)
-        block_matTvec<T, 0>(b, oX, F + lay.Kneg, rX, n, n);
-        Mat::sync(b);
+        // oX = Kneg rX - M^T oZ + NTn^T rY     (Kneg = -K, NTn = -N^T; the first term from above)
         block_matvec16<T, 2>(b, oX, F + lay.MT, oZ, n, m);
         if (q > 0) {
             Mat::sync(b);
@@ -1250,7 +1256,11 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
         }
         Mat::sync(b);
     };
-    apply(vRX, vRY, vRH, vDZ, vDX, vDY);
+    auto apply = [&](const T* rX, const T* rY, T* rH, T* oZ, T* oX, T* oY) {
+        products(rX, rY, rH, oX);
+        finish(rX, rY, rH, oZ, oX, oY);
+    };
+    finish(vRX, vRY, vRH, vDZ, vDX, vDY);
 
     // Iterative refinement on the residual of the ORIGINAL KKT system (batch.py:244-270, solve_kkt_ir; the factor
     // is re-used, not re-computed as there):  res = K sol + rhs  with the caller's Q, G, A,  sol += K~^-1 (-res).
