@@ -112,8 +112,8 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4 (four waves at 4 or 7 tile rows = the chain-wave form, which is the default there); by default the
  * library picks by dtype and size.  Bit 14 (16384): qpx_pre_factor by the symmetric sweep on the thread grid also
- * where its matrix-core form serves the size (float64 arithmetic, neq = 0, 49 <= nz <= 112, nineq <= 112: a
- * factorisation of Q + tile products, qpx_prefac.h; same blob).  (Bit 15, and bit 14 until v6, selected two round-3
+ * where its matrix-core form serves the size (float64 arithmetic, 49 <= nz + neq <= 112, nineq <= 112: a
+ * factorisation of Q -- of [[Q, A^T], [A, 0]] -- + tile products, qpx_prefac.h; same blob).  (Bit 15, and bit 14 until v6, selected two round-3
  * forms -- a pre-factorisation by a sweep on matrix-core tiles and the four-wave tile kernels without their chain wave
  * -- that lost their A/Bs and were deleted.)
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a

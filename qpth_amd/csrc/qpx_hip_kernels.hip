@@ -208,22 +208,24 @@ template <int NBL, int NW, bool CH> int launch_polish_tile(const PolishArgs<doub
 QPX_INSTPT(1, 1, false) QPX_INSTPT(2, 1, false) QPX_INSTPT(4, 1, false) QPX_INSTPT(4, 4, true) QPX_INSTPT(7, 4, true)
 #elif QPX_TU_KERNEL == 14
 // pre_factor_kkt on matrix-core tiles (qpx_prefac.h), f64, neq = 0: four waves per QP, two QPs per CU
-template <int NBN> __global__ __launch_bounds__(256, 2) void k_prefac_tile(PrefactorArgs<double> a)
+template <int NBN, bool kEq> __global__ __launch_bounds__(256, 2) void k_prefac_tile(PrefactorArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    prefac_tile_body<NBN>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+    prefac_tile_body<NBN, kEq>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
-template <int NBN> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream)
+template <int NBN, bool kEq> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream)
 {
-    auto kern = k_prefac_tile<NBN>;
+    auto kern = k_prefac_tile<NBN, kEq>;
     static BigLdsFlags big_lds_enabled;
     if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
-template int launch_prefac_tile<4>(const PrefactorArgs<double>&, size_t, void*);
-template int launch_prefac_tile<7>(const PrefactorArgs<double>&, size_t, void*);
+template int launch_prefac_tile<4, false>(const PrefactorArgs<double>&, size_t, void*);
+template int launch_prefac_tile<7, false>(const PrefactorArgs<double>&, size_t, void*);
+template int launch_prefac_tile<4, true>(const PrefactorArgs<double>&, size_t, void*);
+template int launch_prefac_tile<7, true>(const PrefactorArgs<double>&, size_t, void*);
 #elif QPX_TU_KERNEL == 10 || QPX_TU_KERNEL == 11
 // defined below, outside the launcher chain
 #elif QPX_TU_KERNEL == 9

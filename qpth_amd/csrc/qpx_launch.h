@@ -31,7 +31,7 @@ int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream);
 // thread-grid kernels (qpx_grid.h), 16x16 threads per QP, format-3 blob
 template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream);
 template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
-template <int NBN> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream);     // pre_factor_kkt on matrix-core tiles (qpx_prefac.h)
+template <int NBN, bool kEq> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream);     // pre_factor_kkt on matrix-core tiles (qpx_prefac.h)
 template <int NBL, int NW, int NS, bool CH = false> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream);     // matrix-core tiles, f64, NW waves per QP (CH: chain-wave form)
 template <int NBL, int NW, bool kBw, bool CH = false> int launch_kkt_tile(const KktArgs<double>& a, size_t lds_bytes, void* stream);
 template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void* stream);   // 8x8 grid = one wave

@@ -1,4 +1,5 @@
-// qpx_prefac.h -- pre_factor_kkt on the MATRIX CORES (f64, neq = 0, 49 <= nz <= 112, nineq <= 112; round 4).
+// qpx_prefac.h -- pre_factor_kkt on the MATRIX CORES (f64, 49 <= nz + neq <= 112, nineq <= 112; round 4).
+// (Described for neq = 0; equality constraints: the note at prefac_tile_body.)
 //
 // Replaces, at those sizes, the symmetric sweep of the augmented matrix (qpx_grid.h: sweep_body; reference:
 // pre_factor_kkt, qpth/solvers/pdipm/batch.py:375-429) and writes the SAME blob (qpx_layout.h, family (a)): -K = -Q^-1
@@ -40,9 +41,10 @@ QPX_LAYOUT_HD constexpr size_t lds_elems_prefac_tile(int nbn)
     return prefac_fixed_elems(nbn) + u;
 }
 // does the matrix-core pre-factorisation serve this size?  (images: fac_layout's, 4 = the tile image only)
+// (neq > 0, round 4: the factorisation is of the quasi-definite [[Q, A^T], [A, 0]] of order nz + neq <= 112)
 QPX_LAYOUT_HD bool prefac_tile_serves(int n, int m, int q, int images)
 {
-    return q == 0 && images == 4 && (tile_nb(n) == 4 || tile_nb(n) == 7) && tile_nb(m) > 0;
+    return images == 4 && n + q <= 112 && (tile_nb(n + q) == 4 || tile_nb(n + q) == 7) && tile_nb(m) > 0;
 }
 
 // Which wave computes which tile of K and of R (see prefac_tile_body; host side, once per launch): the wave with the
@@ -77,14 +79,20 @@ inline void prefac_deal(int nbn, int n, int m, unsigned (&pf_k)[4], unsigned (&p
         for (int i2 = 0; i2 <= i1; ++i2) pf_r[pick(1)] |= 1u << (i1 * (i1 + 1) / 2 + i2);
 }
 
-template <int NBN>
+// kEq (neq > 0): the same kernel on the augmented matrix Ka = [[Q, A^T], [A, 0]] of order nn = n + q <= 112.  Its
+// un-pivoted factorisation Ka = L~ D L~^T has q negative pivots (-A Q^-1 A^T, the sweep's second batch of pivots); with
+// V = |D|^-1/2 L~^-1 and S = sign(D),  Ka^-1 = V^T S V = [[K, N], [N^T, -S11^-1]]  and with Yt = V [G^T; 0]
+//   [M^T; W^T] = V^T S Yt,   R = Yt^T S Yt
+// -- the products of the neq = 0 kernel with the rows n .. nn - 1 of one operand negated, and three more arrays of the
+// blob read off the rows beyond n of the results: -N^T and S11^-1 from the tiles of Ka^-1, W^T from the rows of M^T.
+template <int NBN, bool kEq = false>
 QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, int qp, double* lds)
 {
     using T = double;
     using TM = TileMat<NBN, 4, true>;
     constexpr int MPN = 16 * NBN, CAP = prefac_cap(NBN), VS = kPfVS, YBS = NBN * 256;
-    const int n = a.n, m = a.m;
-    const FacLayout lay = fac_layout(n, m, 0, a.images);
+    const int n = a.n, m = a.m, q = kEq ? a.q : 0, nn = n + q;          // nn: order of the factorisation
+    const FacLayout lay = fac_layout(n, m, q, a.images);
     T* F = a.fac + (size_t)qp * a.fac_stride;
     const In<T> Qg(a.Q, (size_t)qp * a.sQ, a.io32), Gg(a.G, (size_t)qp * a.sG, a.io32);
     T* rd = lds;                       // 1 / d_k of the factorisation (MPN)
@@ -94,8 +102,9 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
     T* Vs = un;
     T* Yb = un;
     const int nbm = (m + 15) >> 4;     // m-blocks
-    const int nbr = (n + 15) >> 4;     // tile rows of V that are not all padding
-    auto nsl = [n](int k) { const int left = n - 16 * k; return left >= 16 ? 4 : (left <= 0 ? 0 : (left + 3) >> 2); };
+    const int nbr = (nn + 15) >> 4;    // tile rows of V that are not all padding
+    auto sgn = [n, nn](int row) { return (kEq && row >= n && row < nn) ? T(-1) : T(1); };      // S
+    auto nsl = [nn](int k) { const int left = nn - 16 * k; return left >= 16 ? 4 : (left <= 0 ? 0 : (left + 3) >> 2); };
 
     QPX_PROF_INIT
     // ---- P0: V = D^-1/2 L~^-1 of Q
@@ -124,12 +133,34 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
             for (int u = 0; u < 8 * NBN; ++u) {
                 const int row = r0 + 2 * u;
                 const bool ok = row < n && col >= row && col < n;
-                T* dst = ok ? qs + (row * n - (row * (row - 1)) / 2 + col - row) : dump;
+                T* dst = ok ? qs + (row * nn - (row * (row - 1)) / 2 + col - row) : dump;
                 *dst = v[u];
             }
         };
         if (a.io32) stage_q(float());
         else stage_q(double());
+        if constexpr (kEq) {
+            // A^T right of Q (row r of the packed triangle, columns n .. nn - 1), zeros below it
+            auto stage_a = [&](auto tag) {
+                using S = decltype(tag);
+                const GlobalBuf<S> ab(reinterpret_cast<const S*>(a.A) + (size_t)qp * a.sA, (long long)q * n);
+                T v[NBN];                                     // q n <= 16 * 112 = 7 * 256
+#pragma unroll
+                for (int u = 0; u < NBN; ++u) {
+                    const int e = b.tid + 256 * u;
+                    v[u] = ab.at(e < q * n ? e : 0);
+                }
+#pragma unroll
+                for (int u = 0; u < NBN; ++u) {
+                    const int e = b.tid + 256 * u, j = e / n, r = e - j * n;          // A[j][r]
+                    T* dst = e < q * n ? qs + (r * nn - (r * (r - 1)) / 2 + n + j - r) : dump;
+                    *dst = v[u];
+                }
+            };
+            if (a.io32) stage_a(float());
+            else stage_a(double());
+            for (int e = b.tid; e < q * (q + 1) / 2; e += b.nt) qs[n * nn - (n * (n - 1)) / 2 + e] = T(0);    // rows n .. nn - 1
+        }
         b.sync();
     }
     // the tile image of R: zero where nothing is written below (rows / columns of padding, tile rows beyond nbm); behind
@@ -153,8 +184,8 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
                         for (int r = 0; r < 4; ++r) {
                             const int i = 16 * I + p.g + 4 * r, j = 16 * J + p.c;
                             const int lo = i < j ? i : j, hi = i < j ? j : i;       // Q by its upper triangle, like the sweep
-                            const T v = qs[hi < n ? lo * n - (lo * (lo - 1)) / 2 + hi - lo : 0];
-                            E.e[TM::slot(pp, J)][r] = hi < n ? v : (i == j ? T(1) : T(0));
+                            const T v = qs[hi < nn ? lo * nn - (lo * (lo - 1)) / 2 + hi - lo : 0];
+                            E.e[TM::slot(pp, J)][r] = hi < nn ? v : (i == j ? T(1) : T(0));
                         }
                     }
                 }
@@ -162,16 +193,26 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
         }
         b.sync();                                    // the staged Q lies where the factorisation's scratch does
         QPX_PROF(1)
-        const bool ok = TM::ldl_inv(b, p, E, un, rd, n);
+        int fcode = 0;                               // 0, or QPX_ST_Q_NOT_SPD / QPX_ST_A_RANK (= the flag of the pivot block)
+        if constexpr (kEq) {
+            b.template prio<3>();
+            fcode = TM::template factor_role<TM::template role_of<P>::value, false>(b, p, E, un, rd, nbr < NBN ? nbr : NBN, nn, [n, nn](int k) {
+                const int kmax = nn - 16 * k, pos = n - 16 * k;             // pivots of the block; how many of them are Q's
+                return typename TM::PanelOf{kmax, pos >= 16 || pos >= kmax ? 1 : (pos <= 0 ? -1 : 2 + pos)};
+            });
+        } else {
+            fcode = TM::ldl_inv(b, p, E, un, rd, n) ? 0 : 1;
+        }
+        const bool ok = fcode == 0;
         b.sync();                                    // the factorisation's scratch is dead: V goes on top of it
         QPX_PROF(2)
         // D^-1/2 once per row (the square root is a twenty-instruction sequence: per element of V it cost more than the
         // factorisation's last panel)
         T* rsq = gpart;
-        for (int i = p.tid; i < MPN; i += TM::NT) rsq[i] = (ok && i < n) ? sqrt_(rd[i]) : T(1);
+        for (int i = p.tid; i < MPN; i += TM::NT) rsq[i] = (ok && i < nn) ? sqrt_(kEq ? abs_(rd[i]) : rd[i]) : T(1);
         b.sync();
         if (p.is_chain()) {
-            if (p.lane == 0) flag[0] = ok ? T(1) : T(0);
+            if (p.lane == 0) flag[0] = (T)fcode;
         } else if (ok) {
 #pragma unroll
             for (int pp = 0; pp < TM::NPOS; ++pp) {
@@ -186,7 +227,7 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
                         for (int r = 0; r < 4; ++r) {
                             const int i = 16 * I + p.g + 4 * r, j = 16 * J + p.c;
                             const T e = E.e[TM::slot(pp, J)][r];
-                            const T lowv = i < n ? e * rs[r] : T(0);             // (rows of padding: the identity)
+                            const T lowv = i < nn ? e * rs[r] : T(0);            // (rows of padding: the identity)
                             Vs[(I * (I + 1) / 2 + J) * VS + (p.g + 4 * r) * 17 + p.c] = j < i ? lowv : (j == i ? rs[r] : T(0));
                         }
                     }
@@ -196,9 +237,9 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
         b.sync();
         QPX_PROF(3)
     });
-    if (flag[0] == T(0)) {
+    if (flag[0] != T(0)) {
         for (size_t e = b.tid; e < lay.total; e += b.nt) F[e] = T(0);
-        if (b.tid == 0) a.status[qp] = QPX_ST_Q_NOT_SPD;
+        if (b.tid == 0) a.status[qp] = flag[0] == T(2) ? QPX_ST_A_RANK : QPX_ST_Q_NOT_SPD;
         return;
     }
 
@@ -278,6 +319,18 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
             }
         }
     };
+    // kEq: from here on a block of Yt is kept as S Yt (rows n .. nn - 1 negated): M^T = V^T (S Yt) as it stands, and in
+    // R = Yt^T S Yt = (S (S Yt))^T (S Yt) the A operand gets the sign back (lds_product, r_tile_reg)
+    auto sign_y = [&](T (&Y)[NBN][4]) {
+        if constexpr (kEq) {
+            int gg = g;
+            QPX_LAUNDER_V(gg);          // (the 28 row predicates are recomputed where they are used: kept, they are 56 scalar registers + spills)
+#pragma unroll
+            for (int k = 0; k < NBN; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Y[k][r] *= sgn(16 * k + gg + 4 * r);
+        }
+    };
     auto mt_block = [&](int i, const T (&Y)[NBN][4]) {
 #pragma unroll
         for (int j0 = 0; j0 < NBN; j0 += 2) {
@@ -303,6 +356,10 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
                 const int r0 = 16 * j0 + g + 4 * r, r1 = r0 + 16;
                 if (col < m && r0 < n) F[lay.MT + (size_t)r0 * m + col] = acc0[r];
                 if (j0 + 1 < NBN && col < m && r1 < n) F[lay.MT + (size_t)r1 * m + col] = acc1[r];
+                if constexpr (kEq) {                 // rows n .. nn - 1 of [M^T; W^T]: W = G N, m x q
+                    if (col < m && r0 >= n && r0 < nn) F[lay.W + (size_t)col * q + (r0 - n)] = acc0[r];
+                    if (j0 + 1 < NBN && col < m && r1 >= n && r1 < nn) F[lay.W + (size_t)col * q + (r1 - n)] = acc1[r];
+                }
             }
         }
     };
@@ -317,6 +374,12 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
             const T* vb = ofs_b(k);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { x[r] = va[rs * r]; y[r] = vb[rs * r]; }
+            if constexpr (kEq) {
+                int gg = g;
+                QPX_LAUNDER_V(gg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] *= sgn(16 * k + gg + 4 * r);
+            }
         };
         fetch(k0, av, bv);
 #pragma unroll 1
@@ -347,6 +410,13 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
                 F[lay.Kneg + (size_t)i * n + j] = -acc[r];
                 if (j1 != j2) F[lay.Kneg + (size_t)j * n + i] = -acc[r];
             }
+            if constexpr (kEq) {                     // rows n .. nn - 1 of Ka^-1: [N^T, -S11^-1]
+                if (i >= n && i < nn && j < n) F[lay.NTn + (size_t)(i - n) * n + j] = -acc[r];
+                if (i >= n && i < nn && j >= n && j < nn) {
+                    F[lay.S11i + (size_t)(i - n) * q + (j - n)] = -acc[r];
+                    if (j1 != j2) F[lay.S11i + (size_t)(j - n) * q + (i - n)] = -acc[r];
+                }
+            }
         }
     };
     // tiles of a lower block triangle by number: t = i (i + 1) / 2 + j
@@ -363,12 +433,14 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
     if (iA >= 0) {
         mask_g(Gop);
         y_block(Gop, YA);
+        sign_y(YA);
         colsum_g(iA, Gop);
         if (iB >= 0) load_g(iB, Gop);
         mt_block(iA, YA);
         if (iB >= 0) {
             mask_g(Gop);
             y_block(Gop, YB);
+            sign_y(YB);
             colsum_g(iB, Gop);
             mt_block(iB, YB);
         }
@@ -409,6 +481,8 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
     auto r_tile_reg = [&](const T (&Y)[NBN][4], int i1, int i2, int slot) {
         T acc[4] = {T(0), T(0), T(0), T(0)}, acc2[4] = {T(0), T(0), T(0), T(0)};
         const T* yb = Yb + (slot < 0 ? 0 : slot) * YBS + lane;
+        int gg = g;
+        QPX_LAUNDER_V(gg);
 #pragma unroll
         for (int k = 0; k < NBN; ++k) {
             T bv[4];
@@ -417,8 +491,9 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (k == NBN - 1 && r >= nsl_) continue;                // (uniform; the last tile row only)
-                if (r & 1) b.mfma16x16x4(Y[k][r], bv[r], acc2);
-                else b.mfma16x16x4(Y[k][r], bv[r], acc);
+                const T av = kEq ? Y[k][r] * sgn(16 * k + gg + 4 * r) : Y[k][r];
+                if (r & 1) b.mfma16x16x4(av, bv[r], acc2);
+                else b.mfma16x16x4(av, bv[r], acc);
             }
         }
 #pragma unroll

@@ -414,8 +414,9 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // reciprocals of its pivots in rd[k0 ..], flag[0] = 1 if a pivot is not positive and finite.  One wave; kmax = the
     // pivots that are not identity padding (>= 16: all; the padded ones are skipped: d = 1, no multipliers, their
     // columns of W are zero).
-    // sign: +1 / -1 = the pivots of this block must all be positive / negative (the equality block of the tile sweep);
-    // flag[0] = 1 / 2 when one is not.
+    // sign: +1 / -1 = the pivots of this block must all be positive / negative, 2 + k = the first k positive and the
+    // rest negative (the equality rows of the pre-factorisation, qpx_prefac.h); flag[0] = 1 / 2 when a pivot that must be
+    // positive / negative is not.
     // (in three steps, so that the chain wave can eliminate the first kPivotHead pivots of the NEXT block in the interval
     // of a panel in which it otherwise waits for the tile waves' operand tiles -- factor_role)
     struct PivotState { T a[4]; T dg, myr, vn; };
@@ -446,9 +447,14 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         // a pivot that is not positive and finite leaves a reciprocal that is not (negative, NaN from inf - inf or
         // 0 * inf further down, 0 or inf); nothing above traps, so one test of the sixteen reciprocals replaces
         // two compares in every pivot's chain
-        const T sr = sign > 0 ? st.myr : ((p.lane < 16 && p.lane < kmax) ? -st.myr : st.myr);     // (skipped pivots keep myr = 1)
-        const bool bad = blk.any(!(sr > T(0) && sr < T(1e300)));
-        if (p.lane == 0) flag[0] = bad ? (sign > 0 ? T(1) : T(2)) : T(0);
+        // sign >= 2 (round 4, the pre-factorisation with equality constraints): a block whose first sign - 2 pivots
+        // must be positive and the rest negative
+        const int split = sign >= 2 ? sign - 2 : (sign > 0 ? 16 : 0);
+        const bool neg = p.lane < 16 && p.lane < kmax && p.lane >= split;
+        const T sr = neg ? -st.myr : st.myr;                               // (skipped pivots keep myr = 1)
+        const bool wrong = !(sr > T(0) && sr < T(1e300));
+        const bool badp = blk.any(wrong && !neg), badn = blk.any(wrong && neg);
+        if (p.lane == 0) flag[0] = badp ? T(1) : (badn ? T(2) : T(0));
     }
     static QPX_DEV void pivot_block(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax, int sign = 1)
     {

@@ -289,12 +289,12 @@ template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t l
     }
     return QPX_OK;
 }
-template <int NBN> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void*)
+template <int NBN, bool kEq> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
         std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
         double* base = reinterpret_cast<double*>(lds.data());
-        run_block(256, [&](const Block& b) { prefac_tile_body<NBN>(b, a, qp, base); });
+        run_block(256, [&](const Block& b) { prefac_tile_body<NBN, kEq>(b, a, qp, base); });
     }
     return QPX_OK;
 }

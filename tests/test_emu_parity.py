@@ -179,31 +179,41 @@ def test_sweep_by_groups_of_four_reports_breakdowns(shape):
             QPFunction(verbose=-1)(Q, p, G, h, Ab, bb)
 
 
-def _grid_blob_regions(n, m):
-    """sub-arrays of the family-(a) blob at neq = 0 with the tile image only (qpx_layout.h: fac_layout(n, m, 0, 4))"""
+def _grid_blob_regions(n, m, q=0):
+    """sub-arrays of the family-(a) blob with the tile image only (qpx_layout.h: fac_layout(n, m, q, 4))"""
     al = lambda x: (x + 3) & ~3
     nbt = [t for t in (1, 2, 4, 7) if (m + 15) // 16 <= t][0]
-    o = al(n * n) + al(n * m)
-    return {"Kneg": (0, n * n), "MT": (al(n * n), n * m), "gt1": (o, 1), "Rm": (o + 12, nbt * (nbt + 1) // 2 * 256)}
+    reg, o = {}, 0
+    for name, size in (("Kneg", n * n), ("MT", n * m), ("NTn", q * n), ("W", m * q), ("S11i", q * q)):
+        if size:
+            reg[name] = (o, size)
+        o += al(size)
+    reg["gt1"] = (o, 1)
+    reg["Rm"] = (o + 12, nbt * (nbt + 1) // 2 * 256)
+    return reg
 
 
 PREFAC_SWEEP = 1 << 14      # include/qpx.h, qpx_set_ipm_variant: pre_factor_kkt by the thread-grid sweep
 
 
 @pytest.mark.parametrize("wide", [False, True])
-@pytest.mark.parametrize("shape", [(2, 100, 100), (1, 70, 50), (1, 64, 64), (1, 50, 112), (1, 112, 3), (1, 81, 17), (1, 97, 111), (1, 49, 1)])
+@pytest.mark.parametrize("shape", [(2, 100, 100), (1, 70, 50), (1, 64, 64), (1, 50, 112), (1, 112, 3), (1, 81, 17), (1, 97, 111), (1, 49, 1),
+                                   (2, 100, 50, 10), (1, 60, 70, 6), (1, 40, 30, 10), (1, 96, 20, 16), (1, 90, 40, 5), (1, 79, 17, 1), (1, 100, 96, 12)])
 def test_matrix_core_prefactorisation_writes_the_sweeps_blob(shape, wide):
     """Round 4: pre_factor_kkt (batch.py:375-429) at neq = 0, 49 <= nz <= 112 is a factorisation of Q + tile products on
     the matrix cores (qpx_prefac.h) instead of the symmetric sweep.  Same blob, array by array: -K, M^T, || G^T 1 || and
-    the tile image of R (padding included: exact zeros in both); float32 tensors in float64 arithmetic too."""
+    the tile image of R (padding included: exact zeros in both); float32 tensors in float64 arithmetic too.  With
+    equality constraints (nz + neq <= 112; the factorisation is of [[Q, A^T], [A, 0]], its last neq pivots negative):
+    -N^T, G N and (A Q^-1 A^T)^-1 as well."""
     from qpth_amd import kkt as _dp
-    B, n, m = shape
+    B, n, m = shape[:3]
+    q = shape[3] if len(shape) > 3 else 0
     rng = np.random.default_rng(n * 1000 + m)
     L = rng.standard_normal((B, n, n))
     dt = torch.float32 if wide else torch.float64
     Q = torch.tensor(L @ L.transpose(0, 2, 1) + 1e-2 * np.eye(n), dtype=dt)
     G = torch.tensor(rng.standard_normal((B, m, n)), dtype=dt)
-    e = torch.empty(0, dtype=dt)
+    e = torch.tensor(rng.standard_normal((B, q, n)), dtype=dt) if q else torch.empty(0, dtype=dt)
     blobs = []
     for variant in (0, PREFAC_SWEEP):
         with emulated(256, variant):
@@ -211,7 +221,7 @@ def test_matrix_core_prefactorisation_writes_the_sweeps_blob(shape, wide):
             fac.raise_on_failure()
             blobs.append(fac.blob.reshape(B, -1).clone())
     assert blobs[0].dtype == torch.float64 and blobs[0].shape == blobs[1].shape
-    for name, (o, ln) in _grid_blob_regions(n, m).items():
+    for name, (o, ln) in _grid_blob_regions(n, m, q).items():
         mine, ref = blobs[0][:, o:o + ln].numpy(), blobs[1][:, o:o + ln].numpy()
         assert np.abs(mine - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), name
         if name == "Rm":
@@ -234,6 +244,29 @@ def test_matrix_core_prefactorisation_reports_a_q_that_is_not_spd():
         z = QPFunction(verbose=-1)(Q, p, G, h, A, b)
         with emulated(256, PREFAC_SWEEP):
             zs = QPFunction(verbose=-1)(Q, p, G, h, A, b)
+    assert rel_err(z.numpy(), zs.numpy()).max() < 1e-9
+
+
+def test_matrix_core_prefactorisation_with_equality_constraints_reports_breakdowns():
+    """neq > 0: the pivots of the Q block must be positive, those of the equality block negative -- also inside ONE block
+    of sixteen that holds both (nz = 100: rows 96 .. 99 and the first equality rows) -- and which of the two failed is
+    what the reference's two messages tell apart (batch.py:382-386, 419-423)."""
+    Q, p, G, h, A, b = [torch.tensor(x) for x in problems.prof_qp(2, 100, 50, 10, seed=3)]
+    with emulated(256, PREFAC_SWEEP):
+        zs = QPFunction(verbose=-1)(Q, p, G, h, A, b)
+    with emulated(256):
+        z = QPFunction(verbose=-1)(Q, p, G, h, A, b)
+        for row in (3, 98):
+            Qb = Q.clone()
+            Qb[1, row, row] = -1.0
+            with pytest.raises(RuntimeError, match="Cannot perform LU factorization on Q"):
+                QPFunction(verbose=-1, check_Q_spd=False)(Qb, p, G, h, A, b)
+        for row in (0, 5, 9):                       # a zero row of A: its pivot is exactly 0
+            Ab, bb = A.clone(), b.clone()
+            Ab[1, row] = 0
+            bb[1, row] = 0
+            with pytest.raises(RuntimeError, match="full row rank"):
+                QPFunction(verbose=-1)(Q, p, G, h, Ab, bb)
     assert rel_err(z.numpy(), zs.numpy()).max() < 1e-9
 
 

@@ -779,20 +779,22 @@ PREFAC_SWEEP = 1 << 14      # include/qpx.h, qpx_set_ipm_variant: pre_factor_kkt
 
 
 @pytest.mark.parametrize("wide", [False, True])
-@pytest.mark.parametrize("shape", [(512, 100, 100), (64, 64, 64), (33, 112, 96), (16, 70, 50), (8, 49, 112), (1024, 100, 10)])
+@pytest.mark.parametrize("shape", [(512, 100, 100), (64, 64, 64), (33, 112, 96), (16, 70, 50), (8, 49, 112), (1024, 100, 10),
+                                   (512, 100, 50, 10), (64, 96, 100, 16), (33, 60, 70, 6), (16, 40, 30, 10), (8, 90, 40, 5)])
 def test_matrix_core_prefactorisation_against_the_sweep(dev, shape, wide):
     """Round 4: pre_factor_kkt (batch.py:375-429) on the matrix cores (qpx_prefac.h; neq = 0, 49 <= nz <= 112) writes the
     blob the symmetric sweep writes -- -K, M^T, || G^T 1 ||, the tile image of R with its zero padding -- at C2's full
     size and at the sizes that exercise its padding paths; float32 tensors in float64 arithmetic too."""
     from qpth_amd import _lib
     from qpth_amd import kkt as _dp
-    B, n, m = shape
+    B, n, m = shape[:3]
+    q = shape[3] if len(shape) > 3 else 0            # neq > 0: the factorisation is of [[Q, A^T], [A, 0]], nz + neq <= 112
     rng = np.random.default_rng(n * 1000 + m)
     L = rng.standard_normal((B, n, n))
     dt = torch.float32 if wide else torch.float64
     Q = torch.tensor(L @ L.transpose(0, 2, 1) + 1e-2 * np.eye(n), dtype=dt, device=dev)
     G = torch.tensor(rng.standard_normal((B, m, n)), dtype=dt, device=dev)
-    e = torch.empty(0, dtype=dt, device=dev)
+    e = torch.tensor(rng.standard_normal((B, q, n)), dtype=dt, device=dev) if q else torch.empty(0, dtype=dt, device=dev)
     blobs = []
     for variant in (0, PREFAC_SWEEP):
         old = _lib.hip().dll.qpx_set_ipm_variant(variant)
@@ -804,17 +806,23 @@ def test_matrix_core_prefactorisation_against_the_sweep(dev, shape, wide):
             _lib.hip().dll.qpx_set_ipm_variant(old)
     al = lambda x: (x + 3) & ~3
     nbt = [t for t in (1, 2, 4, 7) if (m + 15) // 16 <= t][0]
-    o = al(n * n) + al(n * m)
-    regions = {"Kneg": (0, n * n), "MT": (al(n * n), n * m), "gt1": (o, 1), "Rm": (o + 12, nbt * (nbt + 1) // 2 * 256)}
+    regions, o = {}, 0
+    for name, size in (("Kneg", n * n), ("MT", n * m), ("NTn", q * n), ("W", m * q), ("S11i", q * q)):
+        if size:
+            regions[name] = (o, size)
+        o += al(size)
+    regions["gt1"] = (o, 1)
+    regions["Rm"] = (o + 12, nbt * (nbt + 1) // 2 * 256)
     for name, (off, ln) in regions.items():
         mine, ref = blobs[0][:, off:off + ln], blobs[1][:, off:off + ln]
         assert np.abs(mine - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), name
         if name == "Rm":
             assert ((ref == 0) == (mine == 0)).all()
-    # K against numpy
-    K = -blobs[0][:, :n * n].reshape(B, n, n)
-    Kr = np.linalg.inv(Q.double().cpu().numpy())
-    assert np.abs(K - Kr).max() <= 1e-8 * np.abs(Kr).max()
+    # K against numpy (neq = 0: the inverse of Q)
+    if q == 0:
+        K = -blobs[0][:, :n * n].reshape(B, n, n)
+        Kr = np.linalg.inv(Q.double().cpu().numpy())
+        assert np.abs(K - Kr).max() <= 1e-8 * np.abs(Kr).max()
 
 
 def test_matrix_core_prefactorisation_reports_a_q_that_is_not_spd(dev):
@@ -828,6 +836,17 @@ def test_matrix_core_prefactorisation_reports_a_q_that_is_not_spd(dev):
             QPFunction(verbose=-1, check_Q_spd=False)(Qb, p, G, h, A, b)
     z = QPFunction(verbose=-1)(Q, p, G, h, A, b)
     assert torch.isfinite(z).all()
+    # with equality constraints: which block's pivot failed decides the message (batch.py:382-386, 419-423)
+    Q, p, G, h, A, b = to_dev(problems.prof_qp(64, 100, 50, 10, seed=3), dev, grad=False)
+    Qb = Q.clone()
+    Qb[7, 98, 98] = -1.0
+    with pytest.raises(RuntimeError, match="Cannot perform LU factorization on Q"):
+        QPFunction(verbose=-1, check_Q_spd=False)(Qb, p, G, h, A, b)
+    Ab, bb = A.clone(), b.clone()
+    Ab[9, 4] = 0
+    bb[9, 4] = 0
+    with pytest.raises(RuntimeError, match="full row rank"):
+        QPFunction(verbose=-1)(Q, p, G, h, Ab, bb)
 
 
 # ---------------------------------------------------------------- 5. the bench contract
