@@ -144,14 +144,15 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
             auto stage_a = [&](auto tag) {
                 using S = decltype(tag);
                 const GlobalBuf<S> ab(reinterpret_cast<const S*>(a.A) + (size_t)qp * a.sA, (long long)q * n);
-                T v[NBN];                                     // q n <= 16 * 112 = 7 * 256
+                constexpr int NA = (MPN * MPN / 4 + 255) / 256;       // q n <= (nn / 2)^2
+                T v[NA];
 #pragma unroll
-                for (int u = 0; u < NBN; ++u) {
+                for (int u = 0; u < NA; ++u) {
                     const int e = b.tid + 256 * u;
                     v[u] = ab.at(e < q * n ? e : 0);
                 }
 #pragma unroll
-                for (int u = 0; u < NBN; ++u) {
+                for (int u = 0; u < NA; ++u) {
                     const int e = b.tid + 256 * u, j = e / n, r = e - j * n;          // A[j][r]
                     T* dst = e < q * n ? qs + (r * nn - (r * (r - 1)) / 2 + n + j - r) : dump;
                     *dst = v[u];

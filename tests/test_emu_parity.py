@@ -198,7 +198,7 @@ PREFAC_SWEEP = 1 << 14      # include/qpx.h, qpx_set_ipm_variant: pre_factor_kkt
 
 @pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("shape", [(2, 100, 100), (1, 70, 50), (1, 64, 64), (1, 50, 112), (1, 112, 3), (1, 81, 17), (1, 97, 111), (1, 49, 1),
-                                   (2, 100, 50, 10), (1, 60, 70, 6), (1, 40, 30, 10), (1, 96, 20, 16), (1, 90, 40, 5), (1, 79, 17, 1), (1, 100, 96, 12)])
+                                   (2, 100, 50, 10), (1, 60, 70, 6), (1, 40, 30, 10), (1, 96, 20, 16), (1, 90, 40, 5), (1, 79, 17, 1), (1, 100, 96, 12), (1, 64, 64, 40), (1, 60, 30, 50), (1, 30, 20, 28)])
 def test_matrix_core_prefactorisation_writes_the_sweeps_blob(shape, wide):
     """Round 4: pre_factor_kkt (batch.py:375-429) at neq = 0, 49 <= nz <= 112 is a factorisation of Q + tile products on
     the matrix cores (qpx_prefac.h) instead of the symmetric sweep.  Same blob, array by array: -K, M^T, || G^T 1 || and

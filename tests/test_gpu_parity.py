@@ -780,7 +780,7 @@ PREFAC_SWEEP = 1 << 14      # include/qpx.h, qpx_set_ipm_variant: pre_factor_kkt
 
 @pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("shape", [(512, 100, 100), (64, 64, 64), (33, 112, 96), (16, 70, 50), (8, 49, 112), (1024, 100, 10),
-                                   (512, 100, 50, 10), (64, 96, 100, 16), (33, 60, 70, 6), (16, 40, 30, 10), (8, 90, 40, 5)])
+                                   (512, 100, 50, 10), (64, 96, 100, 16), (33, 60, 70, 6), (16, 40, 30, 10), (8, 90, 40, 5), (16, 64, 64, 40), (8, 60, 30, 50)])
 def test_matrix_core_prefactorisation_against_the_sweep(dev, shape, wide):
     """Round 4: pre_factor_kkt (batch.py:375-429) on the matrix cores (qpx_prefac.h; neq = 0, 49 <= nz <= 112) writes the
     blob the symmetric sweep writes -- -K, M^T, || G^T 1 ||, the tile image of R with its zero padding -- at C2's full
