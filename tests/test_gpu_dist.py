@@ -128,3 +128,28 @@ def test_default_bench_line_carries_both_readings_of_the_metric_at_n_gpus(tmp_pa
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["global_batch"] == 512 * world
     x = d["extra"]["c5_strong_scaling"]
     assert x["global_batch"] == 65536 and x["n_gpus"] == world and x["scaling"] == "strong" and x["value"] > 0
+
+
+def test_tensors_on_a_device_that_is_not_current():
+    """One process, two devices: the QP lives on cuda:1 while cuda:0 is the current device.  Every launch of the library
+    -- the pre-factorisation, the loop, the backward and the batch contraction of the shared-parameter gradients -- has
+    to run on the tensors' device and stream (KKTFactors._knob makes it current around each call); the answer is the one
+    cuda:0 gives.  Needs >= 2 visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("MULTI-DEVICE PATH NOT EXERCISED: %d GPU visible on this box (needs >= 2)" % torch.cuda.device_count())
+    from qpth_amd.qp import QPFunction
+    Q, p, G, h, A, b = problems.prof_qp(48, 100, 50, 10, seed=4)
+    outs = []
+    for devi in (0, 1):
+        dev = torch.device("cuda", devi)
+        torch.cuda.set_device(0)                       # the current device stays cuda:0 in both passes
+        Qs = torch.tensor(Q[0], device=dev, requires_grad=True)          # shared by the batch: qpx_batch_outer runs
+        tp = torch.tensor(p, device=dev, requires_grad=True)
+        tG, th, tA, tb = [torch.tensor(x, device=dev) for x in (G, h, A, b)]
+        z = QPFunction(verbose=-1)(Qs, tp, tG[0], th, tA[0], tb)
+        z.backward(torch.ones_like(z))
+        torch.cuda.synchronize(dev)
+        assert z.device == dev and Qs.grad.device == dev and tp.grad.device == dev
+        outs.append((z.detach().cpu().numpy(), Qs.grad.cpu().numpy(), tp.grad.cpu().numpy()))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert rel_err(a_, b_).max() < 1e-9 or np.abs(a_ - b_).max() < 1e-12
