@@ -228,6 +228,31 @@ def test_matrix_core_prefactorisation_writes_the_sweeps_blob(shape, wide):
             assert ((ref == 0) == (mine == 0)).all()          # the padding of the image
 
 
+def test_matrix_core_prefactorisation_random_shapes():
+    """a seeded walk over the sizes the dispatcher gives the matrix-core pre-factorisation (49 <= nz + neq <= 112,
+    nz + neq + nineq <= 208, any split between nz and neq, both dtypes): every array of the blob against the sweep's"""
+    from qpth_amd import kkt as _dp
+    rng = np.random.default_rng(20260925)
+    for _ in range(16):
+        nn = int(rng.integers(49, 113))
+        q = int(rng.integers(0, min(nn // 2, 40) + 1)) if rng.random() < 0.6 else 0
+        n, m, B, wide = nn - q, int(rng.integers(1, min(112, 208 - nn) + 1)), int(rng.integers(1, 3)), bool(rng.random() < 0.3)
+        dt = torch.float32 if wide else torch.float64
+        L = rng.standard_normal((B, n, n))
+        Q = torch.tensor(L @ L.transpose(0, 2, 1) + 1e-1 * np.eye(n), dtype=dt)
+        G = torch.tensor(rng.standard_normal((B, m, n)), dtype=dt)
+        A = torch.tensor(rng.standard_normal((B, q, n)), dtype=dt) if q else torch.empty(0, dtype=dt)
+        blobs = []
+        for variant in (0, PREFAC_SWEEP):
+            with emulated(256, variant):
+                fac = _dp.KKTFactors.build(Q, G, A, wide=wide)
+                fac.raise_on_failure()
+                blobs.append(fac.blob.reshape(B, -1).clone())
+        for name, (o, ln) in _grid_blob_regions(n, m, q).items():
+            mine, ref = blobs[0][:, o:o + ln].numpy(), blobs[1][:, o:o + ln].numpy()
+            assert np.abs(mine - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), (name, B, n, m, q, wide)
+
+
 def test_matrix_core_prefactorisation_reports_a_q_that_is_not_spd():
     """... and a pivot of Q that is not positive raises what the sweep raises (batch.py:382-386), for the QP it belongs to
     only: the healthy QP of the batch still solves when the broken one is taken out."""
