@@ -228,6 +228,25 @@ def test_matrix_core_prefactorisation_writes_the_sweeps_blob(shape, wide):
             assert ((ref == 0) == (mine == 0)).all()          # the padding of the image
 
 
+@pytest.mark.parametrize("name", ["c2s_b4_n100_m100_f64", "c3s_b4_n100_m50_q10_f64", "sudoku_b16_n64_m64_q40_f64"])
+def test_reference_outputs_through_the_matrix_core_prefactorisation(name):
+    """The REFERENCE's own outputs (golden vectors made by the unmodified reference) at sizes whose pre-factorisation is
+    the matrix-core one: C2's and C3's shapes (neq = 0 / 10) and the sudoku QPs (nz = 64, neq = 40: three tile rows of
+    negative pivots), forward and every gradient the reference produced."""
+    g = load_golden(name)
+    if "Q" in g:
+        arrs = [g[k] for k in ("Q", "p", "G", "h", "A", "b")]
+    else:
+        B, n, m, q, seed = [int(v) for v in g["shape"]]
+        arrs = list(problems.prof_qp(B, n, m, q, seed, np.float64))
+    z, grads = run_qpf(arrs, g["dl_dz"], threads=256)
+    assert rel_err(z, g["zhat"]).max() < TOL
+    for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
+        if k in g and gr is not None:
+            assert gr.shape == g[k].shape, k
+            assert np.abs(gr - g[k]).max() <= 10 * TOL * max(1.0, np.abs(g[k]).max()), k
+
+
 def test_matrix_core_prefactorisation_random_shapes():
     """a seeded walk over the sizes the dispatcher gives the matrix-core pre-factorisation (49 <= nz + neq <= 112,
     nz + neq + nineq <= 208, any split between nz and neq, both dtypes): every array of the blob against the sweep's"""
