@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define QPX_ABI_VERSION 6
+#define QPX_ABI_VERSION 7
 
 /* QPX_F32_WIDE (ABI v4): the caller's arrays are float32, `factors` and all arithmetic are float64 -- every `void*`
  * array below except `factors` has float elements, `factors` holds qpx_factor_elems(QPX_F32_WIDE, ...) DOUBLES.  On
@@ -112,14 +112,14 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4 (four waves at 4 or 7 tile rows = the chain-wave form, which is the default there); by default the
  * library picks by dtype and size.  Bit 14 (16384): qpx_pre_factor by the symmetric sweep on the thread grid also
- * where its matrix-core form serves the size (float64 arithmetic, 49 <= nz + neq <= 112, nineq <= 112: a
+ * where its matrix-core form serves the size (float64 arithmetic, 33 <= nz + neq <= 112, nineq <= 112: a
  * factorisation of Q -- of [[Q, A^T], [A, 0]] -- + tile products, qpx_prefac.h; same blob).  (Bit 15, and bit 14 until v6, selected two round-3
  * forms -- a pre-factorisation by a sweep on matrix-core tiles and the four-wave tile kernels without their chain wave
  * -- that lost their A/Bs and were deleted.)
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
  * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
- * synchronisation), 0 = one part; bits 20..24 = initial stagger between the side streams in units of 16 us; bit 25 =
- * the substitutions by four waves per QP instead of sixteen; bit 26 = the mat-vec R z' in front of the factorisation
+ * synchronisation), 0 = one part; bits 20..24 = initial stagger between the side streams in units of 16 us; (bit 25 selected
+ * the four-wave substitutions of round 3 until v7: retired with them); bit 26 = the mat-vec R z' in front of the factorisation
  * in the caller's stream (the round-3 order) instead of beside it on a helper stream; bit 27 =
  * diagonal blocks eliminated by one wave (the round-3 form) instead of four in the chain-wave form; bit 28 = on the
  * thread grid; bit 29 = no XCD-aware tile order.
@@ -128,6 +128,20 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
  * Returns the previous value. */
 int qpx_set_ipm_variant(int variant);
 int qpx_get_ipm_variant(void);      /* the calling thread's current value */
+
+/* v7: tuning values that do not fit the bits of qpx_set_ipm_variant; per host thread, returns the previous value
+ * (QPX_ERR_ARG for an unknown key or a negative value).  None of them changes a result or the layout of `factors`.
+ *   QPX_TUNE_FUSED_FORWARD  qpx_forward as ONE launch where that form is built (f64 arithmetic, neq = 0, matrix-core
+ *                           pre-factorisation and chain-wave loop kernel at the same number of tile rows -- C2's and
+ *                           C5's shapes): 0 = automatic, 1 = never (qpx_pre_factor + qpx_ipm), 2 = always where built
+ *   QPX_TUNE_DEPHASE        tile kernels: the second workgroup of a CU starts this many x ~8 k shader cycles late (0 =
+ *                           together), so that the latency-bound phases of one QP run beside the matrix streams of the
+ *                           other */
+enum { QPX_TUNE_FUSED_FORWARD = 0, QPX_TUNE_DEPHASE = 1, QPX_TUNE_COUNT = 2 };
+int qpx_set_tuning(int key, int value);
+/* v7: 1 if qpx_forward(dtype, B, n, m, q, ...) is ONE kernel launch under the calling thread's knobs (k_fwd_tile), 0 if it
+ * is qpx_pre_factor followed by qpx_ipm (then a caller may as well issue the two itself and read `status` in between). */
+int qpx_forward_is_one_launch(int dtype, int B, int n, int m, int q);
 
 /* May a batch whose Q, G, A are shared be served by ONE factor blob (qpx_pre_factor with B = 1, consumers
  * with sfac = 0)?  Always for the thread-grid / tile kernels; for the workgroup kernels only if qpx_fits_lds. */

@@ -21,6 +21,7 @@ QPX_F32, QPX_F64, QPX_F32_WIDE = 0, 1, 2      # QPX_F32_WIDE: float32 arrays, fl
 ST_Q_NOT_SPD, ST_A_RANK, ST_KKT_BREAKDOWN, ST_INACCURATE, ST_MAXITER, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 STALL_OFF, STALL_REFERENCE, STALL_FLOOR = 0, 1, 2
 FAMILY_WORKGROUP, FAMILY_GRID, FAMILY_TILE, FAMILY_BIG = 0, 1, 2, 3
+TUNE_FUSED_FORWARD, TUNE_DEPHASE = 0, 1        # keys of qpx_set_tuning (include/qpx.h, v7)
 
 _vp, _i, _i64, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 
@@ -36,6 +37,8 @@ _SIGNATURES = {
     "qpx_fits_lds": (_i, [_i, _i, _i, _i]),
     "qpx_set_ipm_variant": (_i, [_i]),
     "qpx_get_ipm_variant": (_i, []),
+    "qpx_set_tuning": (_i, [_i, _i]),
+    "qpx_forward_is_one_launch": (_i, [_i, _i, _i, _i, _i]),
     "qpx_can_share_factors": (_i, [_i, _i, _i, _i]),
     "qpx_big_gemm_r": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
     "qpx_pre_factor": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
@@ -118,7 +121,7 @@ class QpxLib:
                 continue
             fn = getattr(self.dll, name)       # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if strict and self.dll.qpx_abi_version() != 6:
+        if strict and self.dll.qpx_abi_version() != 7:
             raise RuntimeError("qpth_amd: ABI version mismatch in %s" % path)
 
     def check(self, code):
@@ -147,11 +150,11 @@ class QpxLib:
 
     # -- qp.py:92-96 ---------------------------------------------------------------------
     def forward(self, B, n, m, q, Q, p, G, h, A, b, factors, eps, maxIter, notImprovedLim,
-                stall_policy, zhat, nu, lam, slack, iters, status, best_resid, trace=None):
+                stall_policy, zhat, nu, lam, slack, iters, status, best_resid, trace=None, wide=False):
         Qp, Gp, Ap = Param(Q, 3), Param(G, 3), Param(A, 3)
         pp, hp, bp = Param(p, 2), Param(h, 2), Param(b, 2)
         self.check(self.dll.qpx_forward(
-            _dtype_code(factors), B, n, m, q, Qp.ptr, Qp.stride, pp.ptr, pp.stride, Gp.ptr, Gp.stride,
+            _code(factors, wide), B, n, m, q, Qp.ptr, Qp.stride, pp.ptr, pp.stride, Gp.ptr, Gp.stride,
             hp.ptr, hp.stride, Ap.ptr, Ap.stride, bp.ptr, bp.stride, _ptr(factors), float(eps),
             int(maxIter), int(notImprovedLim), int(stall_policy), _ptr(zhat), _ptr(nu), _ptr(lam),
             _ptr(slack), _ptr(iters), _ptr(status), _ptr(best_resid), _ptr(trace), _stream(factors)))

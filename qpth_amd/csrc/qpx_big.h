@@ -500,11 +500,23 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
 }
 
 // ------------------------------------------------------------------------------------------ triangular solve
-// x <- L^-1 xin (dir 0) or x <- L^-T xin (dir 1) for one QP per workgroup, by blocks of 64, every lane a ROW of the
-// block so that nothing is reduced across lanes: for the forward direction the known entries c multiply column c
-// of L, i.e. row c of the L^T copy in the upper triangle (64 consecutive elements per wave load); for the backward
-// direction row j of L itself.  The four waves split the known entries and add their partial sums through LDS; the
-// diagonal block is a mat-vec with W_kk (its transpose), read from the copy whose rows are the contiguous ones.
+// x <- L^-1 xin (dir 0) or x <- L^-T xin (dir 1) for one QP per workgroup of sixteen waves, by blocks of 64.
+// (round 5) BOTH directions read the LOWER triangle of the factor and the one copy W_kk of a diagonal block's inverse:
+// the copy of L^T that rounds 2-4 kept above the diagonal (for the forward direction's access pattern) doubled the
+// factor's footprint -- 2 MB + 0.13 MB per QP at C4, 270 MB for the batch against an Infinity Cache of 256 MB, read four
+// times per pass by the two solves -- and cost 115 MB of mirrored writes per factorisation.  Wave w owns rows
+// w, w + 16, w + 32, w + 48 of every 64 x 64 block; one load instruction is one 512-byte row segment.
+//   forward  (block row k, blocks (k, j), j < k):  the wave's rows are OUTPUT rows -- a row dot with x_j, summed over
+//            the lanes (DPP butterfly, no LDS); the diagonal block the same way with the rows of W_kk;
+//   backward (block column k, blocks (j, k), j > k): the wave's rows are KNOWN entries -- every lane accumulates its
+//            column, the sixteen partial sums meet in LDS; the diagonal block likewise with the rows of W_kk (= columns
+//            of W_kk^T).
+// The matrix entries of a block step do not depend on the solution: the first two off-diagonal blocks of step k + 1 and
+// its rows of W (twelve loads per lane) are issued BEFORE step k's arithmetic and fly under its chain of reductions and
+// barriers -- the round-4 kernel started every step with a cold round trip to HBM (~2 of its ~5 us per step); the rest
+// of a step streams eight loads per lane at a time.  (All of a step one step ahead -- 2 x 32 doubles per lane -- does not
+// fit the 128 registers of a sixteen-wave workgroup.)  The barriers of this kernel therefore wait for LDS traffic only
+// (Block::sync_lds): the waves exchange nothing through global memory.
 template <class T> struct BigTrsvArgs {
     int B, nb, dir, post;
     const T* M; size_t sM; int ld;
@@ -512,25 +524,42 @@ template <class T> struct BigTrsvArgs {
     const T* xin; size_t sxin;            // right-hand side (may be the same array as x)
     T* x; size_t sx;
     const int* ctrl; size_t sctrl; int check_stop;
-    int nw;                               // waves per QP: 4 (round 3) or 16 (launcher only)
 };
-QPX_LAYOUT_HD size_t big_trsv_lds_elems(int np, int nw = 16) { return (size_t)np + (size_t)(nw + 1) * kBB; }
+constexpr int kTrsvNW = 16;                    // waves per QP
+constexpr int kTrsvRows = kBB / kTrsvNW;       // rows of a block a wave owns
+constexpr int kTrsvPrefetch = 2;               // off-diagonal blocks of a step fetched one step ahead
+QPX_LAYOUT_HD size_t big_trsv_lds_elems(int np) { return (size_t)np + (size_t)(kTrsvNW + 1) * kBB; }
 
-// NW waves per QP (4, or 16 since round 4): the substitution is a chain of block steps whose off-diagonal part is a
-// stream of 512-byte row loads -- with four waves a CU had 16 KB in flight, a quarter of what its share of the HBM
-// bandwidth needs at ~1.5 us of latency; sixteen waves split the known entries four times finer.
-template <class T, int NW> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<T>& a, int qp, T* lds)
+template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<T>& a, int qp, T* lds)
 {
     if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
+    constexpr int NW = kTrsvNW, RW = kTrsvRows, PF = kTrsvPrefetch;
     const int np = a.nb * kBB;
     T* xs = lds;                 // the vector
-    T* part = xs + np;           // NW x 64 partial sums
+    T* part = xs + np;           // NW x 64 partial sums (backward direction)
     T* t = part + NW * kBB;      // block right-hand side
     const T* M = a.M + (size_t)qp * a.sM;
+    const T* Wq = a.W + (size_t)qp * a.sW;
     T* x = a.x + (size_t)qp * a.sx;
     const T* xin = a.xin + (size_t)qp * a.sxin;
-    for (int i = b.tid; i < np; i += b.nt) xs[i] = xin[i];
     const int lane = b.lane(), w = b.uniform(b.wave());
+    const int dir = a.dir, nb = a.nb;
+    // rows w + 16 u of off-diagonal block jb of step k (forward: block (k, jb); backward: block (k + 1 + jb, k)), element `lane`
+    auto rows_of = [&](int k, int jb) {
+        return M + (dir == 0 ? big_blk(a.ld, k, jb) : big_blk(a.ld, k + 1 + jb, k)) + (size_t)w * kBB + lane;
+    };
+    auto ld_rows = [&](const T* p, T (&v)[RW]) {
+#pragma unroll
+        for (int u = 0; u < RW; ++u) v[u] = p[(size_t)u * NW * kBB];
+    };
+    // what step k starts from: its first PF off-diagonal blocks and the rows of W_kk
+    auto prefetch = [&](int k, T (&pm)[PF][RW], T (&pw)[RW]) {
+        const int nblk = dir == 0 ? k : nb - 1 - k;
+#pragma unroll
+        for (int jb = 0; jb < PF; ++jb)
+            if (jb < nblk) ld_rows(rows_of(k, jb), pm[jb]);
+        ld_rows(Wq + (size_t)k * 2 * kBB * kBB + (size_t)w * kBB + lane, pw);
+    };
     auto gather = [&](int i) {
         T sum = T(0);
 #pragma unroll
@@ -538,54 +567,87 @@ template <class T, int NW> QPX_DEV void big_trsv_body(const Block& b, const BigT
             sum += (part[ww * kBB + i] + part[(ww + 1) * kBB + i]) + (part[(ww + 2) * kBB + i] + part[(ww + 3) * kBB + i]);
         return sum;
     };
-    for (int kk = 0; kk < a.nb; ++kk) {
-        const int k = a.dir == 0 ? kk : a.nb - 1 - kk;
+    T pm[PF][RW], pw[RW];
+#pragma unroll
+    for (int jb = 0; jb < PF; ++jb)
+#pragma unroll
+        for (int u = 0; u < RW; ++u) pm[jb][u] = T(0);
+    prefetch(dir == 0 ? 0 : nb - 1, pm, pw);
+    for (int i = b.tid; i < np; i += b.nt) xs[i] = xin[i];
+    b.sync_lds();
+    for (int kk = 0; kk < nb; ++kk) {
+        const int k = dir == 0 ? kk : nb - 1 - kk;
         const int k0 = k * kBB;
-        const int c0 = a.dir == 0 ? 0 : k0 + kBB, c1 = a.dir == 0 ? k0 : np;      // known entries
-        b.sync();
-        // W_kk (W_kk^T) entries of the diagonal mat-vec: independent of everything computed below, so they are
-        // fetched first and fly under the off-diagonal loop
-        const T* Wg = a.W + (size_t)qp * a.sW + (size_t)k * 2 * kBB * kBB + (a.dir == 0 ? kBB * kBB : 0) + lane;
-        T wv[kBB / NW];
+        const int nblk = dir == 0 ? k : nb - 1 - k;
+        T cm[PF][RW], cw[RW];
 #pragma unroll
-        for (int u = 0; u < kBB / NW; ++u) wv[u] = Wg[(w + NW * u) * kBB];
-        {
-            // rows c of the stored matrix (L^T above the diagonal for dir 0, L below it for dir 1), element k0 + lane;
-            // eight independent loads in flight per lane (sixteen measured no better: profiles/r04j)
-            // (row c of block column k: block (c / 64, k), its row c % 64 -- consecutive rows are consecutive memory)
-            auto at = [&](int c) { return M[big_blk(a.ld, c >> 6, k) + (size_t)(c & 63) * kBB + lane]; };
-            T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
-            int c = c0 + w;
-            for (; c + 7 * NW < c1; c += 8 * NW) {
-                const T m0 = at(c), m1 = at(c + NW), m2 = at(c + 2 * NW);
-                const T m3 = at(c + 3 * NW), m4 = at(c + 4 * NW), m5 = at(c + 5 * NW);
-                const T m6 = at(c + 6 * NW), m7 = at(c + 7 * NW);
-                a0 = fma_(m0, xs[c], a0);
-                a1 = fma_(m1, xs[c + NW], a1);
-                a2 = fma_(m2, xs[c + 2 * NW], a2);
-                a3 = fma_(m3, xs[c + 3 * NW], a3);
-                a4 = fma_(m4, xs[c + 4 * NW], a4);
-                a5 = fma_(m5, xs[c + 5 * NW], a5);
-                a6 = fma_(m6, xs[c + 6 * NW], a6);
-                a7 = fma_(m7, xs[c + 7 * NW], a7);
+        for (int jb = 0; jb < PF; ++jb)
+#pragma unroll
+            for (int u = 0; u < RW; ++u) cm[jb][u] = pm[jb][u];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) cw[u] = pw[u];
+        if (kk + 1 < nb) prefetch(dir == 0 ? k + 1 : k - 1, pm, pw);
+        // acc[u]: forward -- the dot of output row w + 16 u with the known x, one partial product per lane;
+        //         backward -- the known rows w + 16 u times their x, accumulated per lane (= per output column)
+        T acc[RW];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) acc[u] = T(0);
+        // x of off-diagonal block jb as this lane needs it: forward x_j[lane]; backward x_j[w + 16 u]
+        auto mac = [&](int jb, const T (&mv)[RW]) {
+            if (dir == 0) {
+                const T xv = xs[jb * kBB + lane];
+#pragma unroll
+                for (int u = 0; u < RW; ++u) acc[u] = fma_(mv[u], xv, acc[u]);
+            } else {
+                const T* xj = xs + (k + 1 + jb) * kBB + w;
+#pragma unroll
+                for (int u = 0; u < RW; ++u) acc[u] = fma_(mv[u], xj[NW * u], acc[u]);
             }
-            for (; c < c1; c += NW) a0 = fma_(at(c), xs[c], a0);
-            part[w * kBB + lane] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+        };
+        // the blocks beyond the prefetched ones stream through two blocks (eight loads per lane) at a time
+        for (int jb = PF; jb < nblk; jb += 2) {
+            T m0[RW], m1[RW];
+            const bool two = jb + 1 < nblk;
+            ld_rows(rows_of(k, jb), m0);
+            ld_rows(rows_of(k, two ? jb + 1 : jb), m1);
+            mac(jb, m0);
+            if (two) mac(jb + 1, m1);
         }
-        b.sync();
-        if (b.tid < kBB) t[b.tid] = xs[k0 + b.tid] - gather(b.tid);
-        b.sync();
-        {
-            // x_k = W t (dir 0: rows of W^T are the contiguous ones) or W^T t (dir 1: rows of W)
-            T acc = 0;
 #pragma unroll
-            for (int u = 0; u < kBB / NW; ++u) acc = fma_(wv[u], t[w + NW * u], acc);
-            part[w * kBB + lane] = acc;
+        for (int jb = 0; jb < PF; ++jb)
+            if (jb < nblk) mac(jb, cm[jb]);
+        if (dir == 0) {
+            // t_i = b_i - sum_j L(k, j)[i][:] . x_j for the wave's four rows i; then x_i = W_kk[i][:] . t
+#pragma unroll
+            for (int u = 0; u < RW; ++u) acc[u] = wave_sum(b, acc[u]);
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < RW; ++u) t[w + NW * u] = xs[k0 + w + NW * u] - acc[u];
+            }
+            b.sync_lds();
+            const T tv = t[lane];
+#pragma unroll
+            for (int u = 0; u < RW; ++u) acc[u] = wave_sum(b, cw[u] * tv);
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < RW; ++u) xs[k0 + w + NW * u] = acc[u];
+            }
+            b.sync_lds();
+        } else {
+            // t_i = b_i - sum_j sum_c L(j, k)[c][i] x_j[c] over the wave's rows c; then x_i = sum_c W_kk[c][i] t[c]
+            part[w * kBB + lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            b.sync_lds();
+            if (b.tid < kBB) t[b.tid] = xs[k0 + b.tid] - gather(b.tid);
+            b.sync_lds();
+            T s2 = T(0);
+#pragma unroll
+            for (int u = 0; u < RW; ++u) s2 = fma_(cw[u], t[w + NW * u], s2);
+            part[w * kBB + lane] = s2;
+            b.sync_lds();
+            if (b.tid < kBB) xs[k0 + b.tid] = gather(b.tid);
+            b.sync_lds();
         }
-        b.sync();
-        if (b.tid < kBB) xs[k0 + b.tid] = gather(b.tid);
     }
-    b.sync();
     for (int i = b.tid; i < np; i += b.nt) x[i] = a.post ? -xs[i] : xs[i];
 }
 
@@ -774,7 +836,12 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
         return;
     }
     if (ctrl[bcStop]) return;
-    if (ctrl[bcFail]) {                          // a loop factorisation broke down: keep the best iterate
+    // a loop factorisation broke down: keep the best iterate.  Phase 2 behind the factorisation (split: the order in which
+    // R z' runs beside it) first lets the iterate it was given compete for best and takes its stop decision -- that iterate
+    // is complete, only the factorisation FOR THE NEXT STEP failed -- and honours the breakdown only if the QP would have
+    // gone on (a converged QP's extra factorisation meets slacks of 1e-30: its breakdown is not the QP's).
+    const bool late_fail = a.phase == 2 && a.split;
+    if (ctrl[bcFail] && !late_fail) {
         if (lane == 0) { ctrl[bcSt] |= QPX_ST_KKT_BREAKDOWN; ctrl[bcStop] = 1; }
         if (a.phase == 1) for (int i = lane; i < m; i += kWave) { vBZ[i] = T(1); vBS[i] = T(1); }
         return;
@@ -864,8 +931,13 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
         if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-2) * feas) stopf = 1;
         const bool bad = !finite_(resid);
         if (bad) stopf = 1;
+        const int failed = late_fail ? ctrl[bcFail] : 0;
+        const bool broke = failed && !stopf;
+        if (broke) stopf = 1;
         b.wave_sync();
         if (lane == 0) {
+            if (broke) ctrl[bcSt] |= QPX_ST_KKT_BREAKDOWN;
+            else if (failed) ctrl[bcFail] = failed & ~QPX_ST_KKT_BREAKDOWN;     // stopped anyway: the factorisation was never needed
             sc[bsMu] = mu; sc[bsSzdot] = szdot;
             ctrl[bcIters] = it + 1;
             if (better) { sc[bsBres] = bres; sc[bsBtau] = tau; }
@@ -1099,7 +1171,7 @@ template <class T> struct BigSolveArgs {
     int negate, post_phase;      // post_phase < 0: none
     int pre_phase;               // > 0: the wave-0 phase that writes the right-hand side (and the stop flag) first
 };
-template <class T, int NS, int NW> QPX_DEV void big_solve_body(const Block& b, const BigSolveArgs<T>& a, int qp, T* lds)
+template <class T, int NS> QPX_DEV void big_solve_body(const Block& b, const BigSolveArgs<T>& a, int qp, T* lds)
 {
     if (a.pre_phase > 0) {
         if (b.uniform(b.wave()) == 0) {
@@ -1111,10 +1183,10 @@ template <class T, int NS, int NW> QPX_DEV void big_solve_body(const Block& b, c
     }
     BigTrsvArgs<T> t = a.t;
     t.dir = 0; t.post = 0;
-    big_trsv_body<T, NW>(b, t, qp, lds);
+    big_trsv_body<T>(b, t, qp, lds);
     b.sync();
     t.dir = 1; t.post = a.negate; t.xin = a.t.x; t.sxin = a.t.sx;
-    big_trsv_body<T, NW>(b, t, qp, lds);
+    big_trsv_body<T>(b, t, qp, lds);
     if (a.post_phase >= 0) {
         b.sync();                                    // the solution is in global memory for wave 0
         if (b.uniform(b.wave()) == 0) {

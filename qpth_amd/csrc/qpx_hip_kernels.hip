@@ -8,7 +8,8 @@
 // 3 = kkt/backward, 5 = sweep pre-factorisation (16x16 thread grid),
 // 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only),
 // 10 = batch-mean outer products of shared-parameter gradients, 11 = the large-QP family (qpx_big.h),
-// 13 = the finishing stage on matrix-core tiles (f64 only; its thread-grid form lives in 7), 14 = pre_factor_kkt on matrix-core tiles (f64 only).  (12 was the sweep
+// 13 = the finishing stage on matrix-core tiles (f64 only; its thread-grid form lives in 7), 14 = pre_factor_kkt on matrix-core tiles (f64 only),
+// 15 = qpx_forward as one launch (14's body + 9's chain-wave loop, f64 only).  (12 was the sweep
 // pre-factorisation on matrix-core tiles of round 3: parity-green, never faster than the thread-grid sweep, deleted in round 4.)
 #include <hip/hip_runtime.h>
 
@@ -212,6 +213,12 @@ template <int NBN, bool kEq> __global__ __launch_bounds__(256, 2) void k_prefac_
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
+    if (a.dephase > 0) {             // A/B (QPX_TUNE_DEPHASE): see k_fwd_tile
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if ((hw >> 16) & 1)
+            for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     prefac_tile_body<NBN, kEq>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
 template <int NBN, bool kEq> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream)
@@ -226,6 +233,40 @@ template int launch_prefac_tile<4, false>(const PrefactorArgs<double>&, size_t, 
 template int launch_prefac_tile<7, false>(const PrefactorArgs<double>&, size_t, void*);
 template int launch_prefac_tile<4, true>(const PrefactorArgs<double>&, size_t, void*);
 template int launch_prefac_tile<7, true>(const PrefactorArgs<double>&, size_t, void*);
+#elif QPX_TU_KERNEL == 15
+// qpx_forward as ONE launch (round 5): pre_factor_kkt on the matrix cores (qpx_prefac.h) and the chain-wave loop
+// kernel (qpx_tile.h) back to back in the same workgroup -- no launch boundary, no chip-wide wait for the slowest
+// pre-factorisation before the first loop iteration, and the blob the loop's prologue reads is what this workgroup wrote
+// a moment ago (L2).  The blob is still written in full: the backward launch reads it.
+template <int NBN, int NS> __global__ __launch_bounds__(256, 2) void k_fwd_tile(FwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    double* lds = reinterpret_cast<double*>(qpx_smem);
+    if (a.dephase > 0) {
+        // A/B (QPX_TUNE_DEPHASE): the second workgroup of a CU (HW_ID.tg_id odd) starts a.dephase x ~8 k cycles late, so that
+        // the latency-bound phases of one QP sit beside the matrix streams of the other
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if ((hw >> 16) & 1)
+            for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    prefac_tile_body<NBN, false>(b, a.pre, (int)blockIdx.x, lds);
+    b.sync();                        // every store of the blob has left this CU ...
+    __threadfence();                 // ... and no stale line of it is read back
+    b.sync();
+    ipm_tile_body<NBN, 4, NS, true>(b, a.ipm, (int)blockIdx.x, lds);
+}
+template <int NBN, int NS> int launch_fwd_tile(const FwdArgs& a, size_t lds_bytes, void* stream)
+{
+    auto kern = k_fwd_tile<NBN, NS>;
+    static BigLdsFlags big_lds_enabled;
+    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.pre.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+template int launch_fwd_tile<7, 2>(const FwdArgs&, size_t, void*);
+template int launch_fwd_tile<4, 1>(const FwdArgs&, size_t, void*);
 #elif QPX_TU_KERNEL == 10 || QPX_TU_KERNEL == 11
 // defined below, outside the launcher chain
 #elif QPX_TU_KERNEL == 9
@@ -239,6 +280,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ipm_tile(IpmArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
+    if (a.dephase > 0) {             // A/B (QPX_TUNE_DEPHASE): see k_fwd_tile
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if ((hw >> 16) & 1)
+            for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     ipm_tile_body<NBL, NW, NS, CH>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
 template <int NBL, int NW, int NS, bool CH> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
@@ -345,11 +392,11 @@ template <class T, bool kFuse> __global__ __launch_bounds__(256, (kFuse ? 2 : 4)
     big_gemm_where(a, ntiles, swz, qp, tile);
     big_gemm2_body<T, kFuse>(b, a, qp, tile, reinterpret_cast<T*>(qpx_smem));
 }
-template <class T, int NW> __global__ __launch_bounds__(64 * NW) void k_big_trsv(BigTrsvArgs<T> a)
+template <class T> __global__ __launch_bounds__(64 * kTrsvNW) void k_big_trsv(BigTrsvArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    big_trsv_body<T, NW>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+    big_trsv_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
 }
 QPX_BIG_KERNEL(k_big_gemv, BigGemvArgs, (big_gemv_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
 QPX_BIG_KERNEL(k_big_vec, BigVecArgs, (big_vec_body<T>(b, a, (int)blockIdx.x)), 256)
@@ -359,11 +406,11 @@ template <class T, int NS> __global__ __launch_bounds__(64) void k_big_phase(Big
     const Block b{(int)threadIdx.x, (int)blockDim.x};
     big_phase_body<T, NS>(b, a, (int)blockIdx.x);
 }
-template <class T, int NS, int NW> __global__ __launch_bounds__(64 * NW) void k_big_solve(BigSolveArgs<T> a)
+template <class T, int NS> __global__ __launch_bounds__(64 * kTrsvNW) void k_big_solve(BigSolveArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    big_solve_body<T, NS, NW>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+    big_solve_body<T, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
 }
 template <class T, int NS> __global__ __launch_bounds__(256) void k_big_diag(BigDiagArgs<T> a)
 {
@@ -394,10 +441,8 @@ template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* s)
 }
 template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* s)
 {
-    static BigLdsFlags f, f16;
-    const size_t lds = big_trsv_lds_elems(a.nb * kBB) * sizeof(T);
-    if (a.nw == 4) return big_launch(k_big_trsv<T, 4>, a, a.B, 1, 256, lds, s, f);
-    return big_launch(k_big_trsv<T, 16>, a, a.B, 1, 1024, lds, s, f16);
+    static BigLdsFlags f;
+    return big_launch(k_big_trsv<T>, a, a.B, 1, 64 * kTrsvNW, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f);
 }
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* s)
 {
@@ -420,22 +465,14 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* s)
 }
 template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* s)
 {
-    static BigLdsFlags f, f16;
+    static BigLdsFlags f;
     const size_t lds = big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T);
     const int ns = big_pad(a.ph.m) / kWave;
-    if (a.t.nw == 4) {
-        switch (ns) {
-        case 1: return big_launch(k_big_solve<T, 1, 4>, a, a.t.B, 1, 256, lds, s, f);
-        case 2: return big_launch(k_big_solve<T, 2, 4>, a, a.t.B, 1, 256, lds, s, f);
-        case 3: case 4: return big_launch(k_big_solve<T, 4, 4>, a, a.t.B, 1, 256, lds, s, f);
-        default: return big_launch(k_big_solve<T, 8, 4>, a, a.t.B, 1, 256, lds, s, f);
-        }
-    }
     switch (ns) {
-    case 1: return big_launch(k_big_solve<T, 1, 16>, a, a.t.B, 1, 1024, lds, s, f16);
-    case 2: return big_launch(k_big_solve<T, 2, 16>, a, a.t.B, 1, 1024, lds, s, f16);
-    case 3: case 4: return big_launch(k_big_solve<T, 4, 16>, a, a.t.B, 1, 1024, lds, s, f16);
-    default: return big_launch(k_big_solve<T, 8, 16>, a, a.t.B, 1, 1024, lds, s, f16);
+    case 1: return big_launch(k_big_solve<T, 1>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
+    case 2: return big_launch(k_big_solve<T, 2>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
+    case 3: case 4: return big_launch(k_big_solve<T, 4>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
+    default: return big_launch(k_big_solve<T, 8>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
     }
 }
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* s)

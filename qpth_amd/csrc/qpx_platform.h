@@ -51,6 +51,15 @@ struct Block {
         __syncthreads();
     }
 
+    // workgroup barrier for kernels whose waves exchange data through LDS ONLY: global loads issued before it stay in
+    // flight across it (sync() drains them).  big_trsv_body prefetches a block step ahead under its barriers.
+    QPX_DEV void sync_lds() const
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
     // ordering point for LDS traffic between lanes of ONE wave.  A wave's DS instructions
     // execute in issue order, so only the compiler must be kept from moving them.
     QPX_DEV void wave_sync() const

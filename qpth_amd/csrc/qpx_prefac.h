@@ -1,4 +1,4 @@
-// qpx_prefac.h -- pre_factor_kkt on the MATRIX CORES (f64, 49 <= nz + neq <= 112, nineq <= 112; round 4).
+// qpx_prefac.h -- pre_factor_kkt on the MATRIX CORES (f64, 33 <= nz + neq <= 112, nineq <= 112; round 4).
 // (Described for neq = 0; equality constraints: the note at prefac_tile_body.)
 //
 // Replaces, at those sizes, the symmetric sweep of the augmented matrix (qpx_grid.h: sweep_body; reference:
@@ -522,5 +522,12 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
     QPX_PROF_DUMP(F + lay.prof, T)
     if (b.tid == 0) a.status[qp] = 0;
 }
+
+// qpx_forward as one launch (k_fwd_tile): the argument blocks of both bodies
+struct FwdArgs {
+    PrefactorArgs<double> pre;
+    IpmArgs<double> ipm;
+    int dephase;
+};
 
 }  // namespace qpx

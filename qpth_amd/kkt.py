@@ -99,6 +99,11 @@ class KKTFactors:
         # does the kernel family that serves this size refine KKT solves in the kernel (qpx_factor_solve_kkt(..., refine))?
         # (a pre-v5 build loaded non-strictly by scripts/ab_bench.py has no such symbol: it ignored `refine` where it could not refine)
         self.refine_ok = bool(self.lib.dll.qpx_refine_supported(code, self.n, self.m, self.q)) if hasattr(self.lib.dll, "qpx_refine_supported") else True
+        # ... and does it have the finishing stage as a kernel (qpx_polish)?  Asked here, under the knob the factors are built
+        # with: the answer depends on the calling thread's knob, and polish() may be reached from another thread
+        pcode = _lib.QPX_F64 if Q.dtype == torch.float64 else _lib.QPX_F32
+        self.polish_ok = (not self.wide and hasattr(self.lib.dll, "qpx_polish_supported")
+                          and bool(self.lib.dll.qpx_polish_supported(pcode, self.n, self.m, self.q)))
         share_ok = bool(self.lib.dll.qpx_can_share_factors(code, self.n, self.m, self.q))
         self.shared = B > 1 and share_ok and _is_shared(Q, B) and _is_shared(G, B) and _is_shared(A, B)
         nblob = 1 if self.shared else B
@@ -230,9 +235,7 @@ a non-zero diagonal.
         kernel launch (qpx_polish, include/qpx.h v6) wherever the thread-grid / tile kernels serve the size; the
         host-driven form below (`_polish_host`) remains for the kernel families without it (large-QP family with
         explicit float32 `refine=k`, the workgroup kernels behind knob 1).  No host sync either way."""
-        dll = self.lib.dll
-        code = _lib.QPX_F64 if self.dtype == torch.float64 else _lib.QPX_F32
-        if not self.wide and hasattr(dll, "qpx_polish_supported") and dll.qpx_polish_supported(code, self.n, self.m, self.q):
+        if self.polish_ok:
             B, n, m, q = self.B, self.n, self.m, self.q
             self._check(p, n, "p")
             self._check(h, m, "h")

@@ -59,7 +59,10 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
       k > 0 -- the float32 kernels + k finishing Newton steps on the residuals of the ORIGINAL problem data
             (KKTFactors.polish -- the reference's KKTSolvers.IR_UNOPT idea, batch.py:244-270; each with one
             in-kernel refinement step per KKT solve, also applied to the backward solve).
-    float64 inputs: None = 0."""
+    float64 inputs: None = 0.
+    Memory: with refine=None a float32 batch in the large-QP family keeps a float64 factor blob (9.4 MB per QP at
+    nz = nineq = 500, twice the float32 family's); a batch that only fits HBM with float32 factors should pass refine=2
+    (float32 kernels + finishing iterations) or refine=0 explicitly."""
     class QPFunctionFn(Function):
         @staticmethod
         def forward(ctx, Q_, p_, G_, h_, A_, b_):

@@ -44,9 +44,14 @@ for blocks in (512, 256, 1024):
             tot += 1
             same += int(tuple(simd[v[0]]) == tuple(simd[v[1]]))
     print("   CUs with two workgroups: %d, of which wave w of both on the same SIMD: %d" % (tot, same))
+    tg = (hw >> 16) & 15
+    print("   HW_ID.tg_id of the workgroups sharing a CU (count):", Counter(tuple(sorted(int(tg[b, 0]) for b in v)) for v in percu.values()).most_common(6))
+    print("   workgroup ids sharing a CU (first 6):", [tuple(v) for v in list(percu.values())[:6]])
     print("   first blocks: ", [(b, int(xcc[b, 0]), int(se[b, 0]), int(cu[b, 0]), tuple(int(x) for x in simd[b])) for b in range(12)])
     print("   start spread (100 MHz ticks): %.0f" % (t0.max() - t0.min()))
 
+if '--placement-only' in sys.argv:
+    sys.exit(0)
 names = {30: "alone", 31: "beside an MFMA stream (no priorities)", 41: "beside a second pivot chain on the same SIMD",
          42: "beside an MFMA stream, pivot at s_setprio 3 / MFMA at 0", 43: "beside a 50 % duty MFMA stream, priorities"}
 for blocks in (1, 256):

@@ -298,6 +298,19 @@ template <int NBN, bool kEq> int launch_prefac_tile(const PrefactorArgs<double>&
     }
     return QPX_OK;
 }
+template <int NBN, int NS> int launch_fwd_tile(const FwdArgs& a, size_t lds_bytes, void*)
+{
+    for (int qp = 0; qp < a.pre.B; ++qp) {
+        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
+        double* base = reinterpret_cast<double*>(lds.data());
+        run_block(256, [&](const Block& b) {
+            prefac_tile_body<NBN, false>(b, a.pre, qp, base);
+            b.sync();
+            ipm_tile_body<NBN, 4, NS, true>(b, a.ipm, qp, base);
+        });
+    }
+    return QPX_OK;
+}
 template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
@@ -390,10 +403,7 @@ template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void*)
 }
 template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void*)
 {
-    if (a.nw == 4)
-        big_grid(a.B, 1, 256, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_trsv_body<T, 4>(b, a, qp, reinterpret_cast<T*>(l)); });
-    else
-        big_grid(a.B, 1, 1024, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_trsv_body<T, 16>(b, a, qp, reinterpret_cast<T*>(l)); });
+    big_grid(a.B, 1, 64 * kTrsvNW, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_trsv_body<T>(b, a, qp, reinterpret_cast<T*>(l)); });
     return QPX_OK;
 }
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void*)
@@ -427,22 +437,13 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void*)
 template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void*)
 {
     const int ns = big_pad(a.ph.m) / kWave;
-    if (a.t.nw == 4)
-        big_grid(a.t.B, 1, 256, big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
-            T* lds = reinterpret_cast<T*>(l);
-            if (ns == 1) big_solve_body<T, 1, 4>(b, a, qp, lds);
-            else if (ns == 2) big_solve_body<T, 2, 4>(b, a, qp, lds);
-            else if (ns <= 4) big_solve_body<T, 4, 4>(b, a, qp, lds);
-            else big_solve_body<T, 8, 4>(b, a, qp, lds);
-        });
-    else
-        big_grid(a.t.B, 1, 1024, big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
-            T* lds = reinterpret_cast<T*>(l);
-            if (ns == 1) big_solve_body<T, 1, 16>(b, a, qp, lds);
-            else if (ns == 2) big_solve_body<T, 2, 16>(b, a, qp, lds);
-            else if (ns <= 4) big_solve_body<T, 4, 16>(b, a, qp, lds);
-            else big_solve_body<T, 8, 16>(b, a, qp, lds);
-        });
+    big_grid(a.t.B, 1, 64 * kTrsvNW, big_trsv_lds_elems(a.t.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
+        T* lds = reinterpret_cast<T*>(l);
+        if (ns == 1) big_solve_body<T, 1>(b, a, qp, lds);
+        else if (ns == 2) big_solve_body<T, 2>(b, a, qp, lds);
+        else if (ns <= 4) big_solve_body<T, 4>(b, a, qp, lds);
+        else big_solve_body<T, 8>(b, a, qp, lds);
+    });
     return QPX_OK;
 }
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void*)

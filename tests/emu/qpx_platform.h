@@ -69,9 +69,11 @@ struct Block {
     int uniform(int v) const { return v; }
 #ifdef QPX_EMU_PTHREADS
     void sync() const { pthread_barrier_wait(&sh->block_bar); }
+    void sync_lds() const { sync(); }
     void wave_sync() const { pthread_barrier_wait(&sh->wave_bar[wave()]); }
 #else
     void sync() const { fiber_wait(sh->sched, &sh->block_bar, nt); }
+    void sync_lds() const { sync(); }
     void wave_sync() const { fiber_wait(sh->sched, &sh->wave_bar[wave()], kWave); }
 #endif
 

@@ -164,7 +164,6 @@ def test_forward_with_every_kkt_solver_matches_the_reference(dev, solver, name):
 def test_refinement_is_refused_where_no_kernel_implements_it(dev):
     """refine > 0 on the large-QP family: QPX_ERR_UNSUPPORTED (ABI v5), not a silently un-refined answer; QPFunction's
     float32 finishing stage there runs with plain solves and keeps the best iterate."""
-    from qpth_amd.qp import QPFunction
     from qpth_amd.solvers.pdipm import batch as pdipm_b
     B, n, m = 4, 300, 300
     arrs = problems.prof_qp(B, n, m, 0, seed=1)
@@ -176,13 +175,8 @@ def test_refinement_is_refused_where_no_kernel_implements_it(dev):
     pdipm_b.solve_kkt(Q_LU, d, G, A, S_LU, rx, rs, rz, None)
     with pytest.raises(RuntimeError, match="not supported"):
         pdipm_b.solve_kkt_ir(Q_LU, d, G, A, S_LU, rx, rs, rz, None, niter=1)
-    z64 = QPFunction(verbose=-1)(Q, p, G, h, A, b).cpu().numpy()
-    t32 = to_dev(arrs, dev, torch.float32, grad=False)
-    z0 = QPFunction(verbose=-1, refine=0)(*t32).cpu().numpy()
-    z2 = QPFunction(verbose=-1, refine=2)(*t32).cpu().numpy()
-    e0, e2 = rel_err(z0, z64).max(), rel_err(z2, z64).max()
-    print("large-QP family, float32, rel err vs f64: refine=0 %.2e  refine=2 %.2e" % (e0, e2))
-    assert e2 <= 2 * e0 + 1e-5
+    # (what the finishing stage achieves at these sizes is pinned against the oracle in
+    # test_large_qp_accuracy_options_against_the_oracle)
 
 
 def test_float32_is_as_close_to_f64_as_the_reference_f32(dev):
@@ -408,8 +402,82 @@ def test_large_qps_with_equality_constraints(dev, B, n, m, q, seed):
     for name, a_, r_ in (("nu", res.nu, y), ("lam", res.lam, lam), ("slacks", res.slacks, s)):
         assert np.abs(a_.cpu().numpy() - r_).max() < 1e-5 * max(1.0, np.abs(r_).max()), name
     # the same QPs as float32 tensors (float64 arithmetic): the float64 answer of the rounded data
-    z32, _ = run_qpf([np.asarray(a_, np.float32) for a_ in (Q, p, G, h, A, b)], dl.astype(np.float32), dev, dtype=torch.float32)
-    print("n=%d m=%d q=%d float32 tensors vs the f64 oracle on the f64 data: max rel err %.2e" % (n, m, q, rel_err(z32, x).max()))
+    # the same QPs as float32 tensors (float64 arithmetic, QPX_F32_WIDE): the float64 answer of the ROUNDED data -- every QP
+    # within 1e-5 of the oracle on that data (the gate of the C4 float32 test), gradients within 1e-5 of their scale
+    arrs32 = [np.asarray(a_, np.float32) for a_ in (Q, p, G, h, A, b)]
+    x32, _, _, _, grads32, _ = orc.qp_forward_backward(*[np.asarray(a_, np.float64) for a_ in arrs32], dl_dz=dl.astype(np.float32).astype(np.float64))
+    z32, mine32 = run_qpf(arrs32, dl.astype(np.float32), dev, dtype=torch.float32)
+    e32 = rel_err(z32, x32)
+    print("n=%d m=%d q=%d float32 tensors vs the f64 oracle on the rounded data: max rel err %.2e (on the f64 data: %.2e)"
+          % (n, m, q, e32.max(), rel_err(z32, x).max()))
+    assert z32.dtype == np.float32 and e32.max() <= 1e-5, e32.max()
+    for k, a_, r_ in zip(("dQ", "dp", "dG", "dh", "dA", "db"), mine32, grads32):
+        assert a_.dtype == np.float32
+        assert np.abs(a_ - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max()), k
+
+
+@pytest.mark.parametrize("shape", [(512, 100, 100), (640, 64, 64), (96, 97, 110)])
+def test_forward_as_one_launch_equals_the_two_launches(dev, shape):
+    """qpx_forward as ONE launch (k_fwd_tile, QPX_TUNE_FUSED_FORWARD = 2) against qpx_pre_factor + qpx_ipm on the same data
+    through the C ABI: same blob, same iterates, same iteration counts (1e-12: the two forms are compiled in different
+    translation units); with the CU's second workgroup started late (QPX_TUNE_DEPHASE) nothing changes either."""
+    from qpth_amd import _lib
+    B, n, m = shape
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, 0, seed=21)
+    tQ, tp, tG, th = to_dev([Q, p, G, h], dev, grad=False)
+    lib = _lib.hip()
+    elems = lib.factor_elems(_lib.QPX_F64, n, m, 0)
+    out = {}
+    for key, (fused, dephase) in {"two": (1, 0), "one": (2, 0), "one_late": (2, 3), "two_late": (1, 2)}.items():
+        blob = torch.zeros(B * elems, dtype=torch.float64, device=dev)
+        st = torch.zeros(B, dtype=torch.int32, device=dev)
+        z, lam, sl = [torch.zeros(B, k, dtype=torch.float64, device=dev) for k in (n, m, m)]
+        it, br = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.float64, device=dev)
+        o1, o2 = lib.dll.qpx_set_tuning(_lib.TUNE_FUSED_FORWARD, fused), lib.dll.qpx_set_tuning(_lib.TUNE_DEPHASE, dephase)
+        try:
+            assert lib.dll.qpx_forward_is_one_launch(_lib.QPX_F64, B, n, m, 0) == (1 if fused == 2 else 0)
+            lib.forward(B, n, m, 0, tQ, tp, tG, th, None, None, blob, 1e-12, 20, 3, _lib.STALL_FLOOR, z, None, lam, sl, it, st, br)
+            torch.cuda.synchronize()
+        finally:
+            lib.dll.qpx_set_tuning(_lib.TUNE_FUSED_FORWARD, o1)
+            lib.dll.qpx_set_tuning(_lib.TUNE_DEPHASE, o2)
+        out[key] = (blob.cpu().numpy(), z.cpu().numpy(), lam.cpu().numpy(), sl.cpu().numpy(), it.cpu().numpy(), st.cpu().numpy())
+    for key in ("one", "one_late", "two_late"):
+        for a_, r_ in zip(out[key][:4], out["two"][:4]):
+            assert np.abs(a_ - r_).max() <= 1e-12 * max(1.0, np.abs(r_).max()), key
+        assert (out[key][4] == out["two"][4]).all() and (out[key][5] == out["two"][5]).all(), key
+
+
+def test_large_qp_accuracy_options_against_the_oracle(dev):
+    """the accuracy options beyond nz+neq+nineq = 208 were only compared with themselves.  At n=300
+    m=200 q=50 (large-QP family): forward(solver=KKTSolvers.IR_UNOPT) in float64 against the oracle at the tolerances of
+    the default path (zhat 1e-6, multipliers 1e-5 of their scale); QPFunction(refine=2) on float32 tensors (the float32
+    kernels + two finishing iterations on float64 residuals of the caller's data) against the oracle's float64 answer
+    on the rounded data: EVERY QP inside the north star's 1e-4 gate, median <= 1e-5 (measured on the kernel bodies: 2.6e-8 /
+    3.3e-7 where the float32 loop alone, refine=0, leaves 2.3e-4 / 4.6e-4)."""
+    from oracle import qp_oracle as orc
+    from qpth_amd import _lib
+    from qpth_amd.qp import QPFunction
+    from qpth_amd.solvers.pdipm import batch as pdipm_b
+    B, n, m, q = 8, 300, 200, 50
+    assert _lib.hip().dll.qpx_kernel_family(_lib.QPX_F64, n, m, q) == _lib.FAMILY_BIG
+    arrs = problems.prof_qp(B, n, m, q, 21)
+    x, y, lam, s, info = orc.OracleQP(*arrs).forward()
+    Q, p, G, h, A, b = to_dev(arrs, dev, grad=False)
+    Q_LU, S_LU, R = pdipm_b.pre_factor_kkt(Q, G, A)
+    xi, yi, zi, si = pdipm_b.forward(Q, p, G, h, A, b, Q_LU, S_LU, R, verbose=-1, solver=pdipm_b.KKTSolvers.IR_UNOPT)
+    assert rel_err(xi.cpu().numpy(), x).max() < TOL
+    for name, a_, r_ in (("nu", yi, y), ("lam", zi, lam), ("slacks", si, s)):
+        assert np.abs(a_.cpu().numpy() - r_).max() < 1e-5 * max(1.0, np.abs(r_).max()), name
+    arrs32 = [np.asarray(a_, np.float32) for a_ in arrs]
+    x32 = orc.OracleQP(*[np.asarray(a_, np.float64) for a_ in arrs32]).forward()[0]
+    t32 = to_dev(arrs32, dev, torch.float32, grad=False)
+    z0 = QPFunction(verbose=-1, refine=0)(*t32).cpu().numpy()
+    z2 = QPFunction(verbose=-1, refine=2)(*t32).cpu().numpy()
+    e0, e2 = rel_err(z0, x32), rel_err(z2, x32)
+    print("n=%d m=%d q=%d float32 kernels vs the f64 oracle on the rounded data: refine=0 median %.2e max %.2e | refine=2 median %.2e max %.2e"
+          % (n, m, q, np.median(e0), e0.max(), np.median(e2), e2.max()))
+    assert np.median(e2) <= 1e-5 and e2.max() <= 1e-4
 
 
 def test_c5_shard_matches_oracle_and_kkt(dev):
@@ -780,9 +848,10 @@ PREFAC_SWEEP = 1 << 14      # include/qpx.h, qpx_set_ipm_variant: pre_factor_kkt
 
 @pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("shape", [(512, 100, 100), (64, 64, 64), (33, 112, 96), (16, 70, 50), (8, 49, 112), (1024, 100, 10),
-                                   (512, 100, 50, 10), (64, 96, 100, 16), (33, 60, 70, 6), (16, 40, 30, 10), (8, 90, 40, 5), (16, 64, 64, 40), (8, 60, 30, 50)])
+                                   (512, 100, 50, 10), (64, 96, 100, 16), (33, 60, 70, 6), (16, 40, 30, 10), (8, 90, 40, 5), (16, 64, 64, 40), (8, 60, 30, 50),
+                                   (16, 36, 40), (8, 30, 100, 10), (8, 33, 20)])      # 33 <= nz + neq <= 48: four tile rows, part padding
 def test_matrix_core_prefactorisation_against_the_sweep(dev, shape, wide):
-    """Round 4: pre_factor_kkt (batch.py:375-429) on the matrix cores (qpx_prefac.h; neq = 0, 49 <= nz <= 112) writes the
+    """Round 4: pre_factor_kkt (batch.py:375-429) on the matrix cores (qpx_prefac.h; 33 <= nz + neq <= 112) writes the
     blob the symmetric sweep writes -- -K, M^T, || G^T 1 ||, the tile image of R with its zero padding -- at C2's full
     size and at the sizes that exercise its padding paths; float32 tensors in float64 arithmetic too."""
     from qpth_amd import _lib
