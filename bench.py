@@ -57,10 +57,17 @@ HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 # micro-benchmarks agree: v_fma_f64 issues every 4.07 ticks per wave (77 TF over 1024 SIMDs at the
 # measured 2.39 GHz tick), v_mfma_f64_16x16x4 every 83 ticks (60 TF) -- scripts/ubench_mfma.py.
 MFMA_PEAK = {"f64": 78.6e12, "f32": 157.3e12}
-# The reference's own PyTorch-CPU PDIPM on this workload, measured in the survey session (SURVEY.md section 6 /
-# 8 threads of a Xeon, MKL LAPACK): it cannot be re-timed on the GPU box (no
-# /root/reference there), so it is quoted next to the port that can.
-REFERENCE_CPU_QPS = {"f64": 222.0, "f32": 629.0}
+# The reference's own PyTorch-CPU PDIPM on this workload cannot be re-timed on the GPU box (no /root/reference there): it
+# is timed in the build container by scripts/ref_cpu_baseline.py (the unmodified reference, all host threads), whose
+# record -- profiles/ref_cpu_baseline.json: QPs/s, thread count, CPU model -- is quoted next to the port that can run here.
+def reference_cpu_record(dtype):
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "ref_cpu_baseline.json")))
+        r = rec["results"][dtype]
+        return {"qps": r["qps"], "threads": rec["threads"], "cpu": rec["cpu"], "config": rec["config"],
+                "source": "profiles/ref_cpu_baseline.json (scripts/ref_cpu_baseline.py, build container)"}
+    except Exception as e:        # a missing or broken record is reported, never replaced by a constant
+        return {"qps": None, "source": "profiles/ref_cpu_baseline.json unreadable: %s" % e}
 
 
 def algorithmic_flops_per_qp(n, m, q, iters):
@@ -471,11 +478,10 @@ def main():
                             "sample": "B=%d QPs of the workload, fwd+bwd, best of 3 at the best OpenMP team size of a "
                                       "scan over 4..128 threads, %s, all %d IPM iterations of the reference's batch-global "
                                       "loop (the GPU loop stops each QP when it has converged: %.1f on average), %d host "
-                                      "CPUs.  The reference's own PyTorch-CPU PDIPM on this workload: %.0f QPs/s (%s, 8 "
-                                      "threads, survey session; it cannot run on the GPU box)"
-                                      % (Bs, args.dtype, int(info["trips"]), iters_mean, ncpu,
-                                         REFERENCE_CPU_QPS[args.dtype], args.dtype),
-                            "reference_pytorch_cpu_qps": REFERENCE_CPU_QPS[args.dtype]}
+                                      "CPUs.  `reference_pytorch_cpu`: the reference's own PyTorch-CPU PDIPM at C2, timed "
+                                      "in the build container (it cannot run on the GPU box)"
+                                      % (Bs, args.dtype, int(info["trips"]), iters_mean, ncpu),
+                            "reference_pytorch_cpu": reference_cpu_record(args.dtype)}
 
         names = {"c2": "C2", "c3": "C3", "c4": "C4", "c5": "C5", "custom": "custom"}
         out = {

@@ -129,20 +129,6 @@ int qpx_fits_lds(int dtype, int n, int m, int q);
 int qpx_set_ipm_variant(int variant);
 int qpx_get_ipm_variant(void);      /* the calling thread's current value */
 
-/* v7: tuning values that do not fit the bits of qpx_set_ipm_variant; per host thread, returns the previous value
- * (QPX_ERR_ARG for an unknown key or a negative value).  None of them changes a result or the layout of `factors`.
- *   QPX_TUNE_FUSED_FORWARD  qpx_forward as ONE launch where that form is built (f64 arithmetic, neq = 0, matrix-core
- *                           pre-factorisation and chain-wave loop kernel at the same number of tile rows -- C2's and
- *                           C5's shapes): 0 = automatic, 1 = never (qpx_pre_factor + qpx_ipm), 2 = always where built
- *   QPX_TUNE_DEPHASE        tile kernels: the second workgroup of a CU starts this many x ~8 k shader cycles late (0 =
- *                           together), so that the latency-bound phases of one QP run beside the matrix streams of the
- *                           other */
-enum { QPX_TUNE_FUSED_FORWARD = 0, QPX_TUNE_DEPHASE = 1, QPX_TUNE_COUNT = 2 };
-int qpx_set_tuning(int key, int value);
-/* v7: 1 if qpx_forward(dtype, B, n, m, q, ...) is ONE kernel launch under the calling thread's knobs (k_fwd_tile), 0 if it
- * is qpx_pre_factor followed by qpx_ipm (then a caller may as well issue the two itself and read `status` in between). */
-int qpx_forward_is_one_launch(int dtype, int B, int n, int m, int q);
-
 /* May a batch whose Q, G, A are shared be served by ONE factor blob (qpx_pre_factor with B = 1, consumers
  * with sfac = 0)?  Always for the thread-grid / tile kernels; for the workgroup kernels only if qpx_fits_lds. */
 int qpx_can_share_factors(int dtype, int n, int m, int q);
@@ -226,7 +212,12 @@ int qpx_polish(int dtype, int B, int n, int m, int q,
  * dQ: u = dx, v = zhat, w = zhat, x = dx, scale = 0.5;  dG: u = dz, v = zhat, w = lam, x = dx, scale = 1;
  * dA: u = dy, v = zhat, w = nu, x = dx.  `out` is (r,c) of dtype, overwritten. */
 int qpx_batch_outer(int dtype, int B, int r, int c, const void* u, const void* v, const void* w,
-                    const void* x, double scale, void* out, qpx_stream_t stream);
+                    const void* x, double scale, void* out, void* ws, size_t ws_elems, qpx_stream_t stream);
+/* v7: `ws` -- ws_elems elements of dtype, at least qpx_batch_outer_workspace_elems(dtype, B, r, c) -- lets a long batch be
+ * contracted in TWO stages: partial tiles per chunk of the batch by many workgroups, then their sum in chunk order (fixed
+ * order: bit-reproducible, no atomics).  NULL / too small / 0 elements needed: one workgroup per 16 x 16 tile of `out`
+ * walks the whole batch, as before -- the same result up to the order of the additions. */
+size_t qpx_batch_outer_workspace_elems(int dtype, int B, int r, int c);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,6 @@ QPX_F32, QPX_F64, QPX_F32_WIDE = 0, 1, 2      # QPX_F32_WIDE: float32 arrays, fl
 ST_Q_NOT_SPD, ST_A_RANK, ST_KKT_BREAKDOWN, ST_INACCURATE, ST_MAXITER, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 STALL_OFF, STALL_REFERENCE, STALL_FLOOR = 0, 1, 2
 FAMILY_WORKGROUP, FAMILY_GRID, FAMILY_TILE, FAMILY_BIG = 0, 1, 2, 3
-TUNE_FUSED_FORWARD, TUNE_DEPHASE = 0, 1        # keys of qpx_set_tuning (include/qpx.h, v7)
 
 _vp, _i, _i64, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 
@@ -37,8 +36,6 @@ _SIGNATURES = {
     "qpx_fits_lds": (_i, [_i, _i, _i, _i]),
     "qpx_set_ipm_variant": (_i, [_i]),
     "qpx_get_ipm_variant": (_i, []),
-    "qpx_set_tuning": (_i, [_i, _i]),
-    "qpx_forward_is_one_launch": (_i, [_i, _i, _i, _i, _i]),
     "qpx_can_share_factors": (_i, [_i, _i, _i, _i]),
     "qpx_big_gemm_r": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
     "qpx_pre_factor": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
@@ -53,7 +50,8 @@ _SIGNATURES = {
     "qpx_polish_supported": (_i, [_i, _i, _i, _i]),
     "qpx_polish": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                         _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "qpx_batch_outer": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp]),
+    "qpx_batch_outer": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp, ctypes.c_size_t, _vp]),
+    "qpx_batch_outer_workspace_elems": (ctypes.c_size_t, [_i, _i, _i, _i]),
 }
 ABI_SYMBOLS = tuple(_SIGNATURES)
 
@@ -192,8 +190,12 @@ class QpxLib:
     def batch_outer(self, u, v, w, x, scale, out):
         B, r = u.shape
         c = v.shape[1]
-        self.check(self.dll.qpx_batch_outer(_dtype_code(out), B, r, c, _ptr(u), _ptr(v), _ptr(w), _ptr(x),
-                                            float(scale), _ptr(out), _stream(out)))
+        code = _dtype_code(out)
+        # long batches: partial tiles per batch chunk in a workspace, summed in chunk order by a second launch
+        need = int(self.dll.qpx_batch_outer_workspace_elems(code, B, r, c))
+        ws = torch.empty(need, dtype=out.dtype, device=out.device) if need else None
+        self.check(self.dll.qpx_batch_outer(code, B, r, c, _ptr(u), _ptr(v), _ptr(w), _ptr(x),
+                                            float(scale), _ptr(out), _ptr(ws), need, _stream(out)))
 
 
 _HIP = None

@@ -8,8 +8,9 @@
 // 3 = kkt/backward, 5 = sweep pre-factorisation (16x16 thread grid),
 // 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only),
 // 10 = batch-mean outer products of shared-parameter gradients, 11 = the large-QP family (qpx_big.h),
-// 13 = the finishing stage on matrix-core tiles (f64 only; its thread-grid form lives in 7), 14 = pre_factor_kkt on matrix-core tiles (f64 only),
-// 15 = qpx_forward as one launch (14's body + 9's chain-wave loop, f64 only).  (12 was the sweep
+// 13 = the finishing stage on matrix-core tiles (f64 only; its thread-grid form lives in 7), 14 = pre_factor_kkt on matrix-core tiles (f64 only).
+// (15 was qpx_forward as ONE launch, round 5 -- 14's body and 9's chain-wave loop in one workgroup: parity-green, 7 % SLOWER at C2
+// and 39 % at B = 8192 n = m = 64, deleted: profiles/r05a_ab_forward_one_launch_*.txt.)  (12 was the sweep
 // pre-factorisation on matrix-core tiles of round 3: parity-green, never faster than the thread-grid sweep, deleted in round 4.)
 #include <hip/hip_runtime.h>
 
@@ -213,12 +214,6 @@ template <int NBN, bool kEq> __global__ __launch_bounds__(256, 2) void k_prefac_
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    if (a.dephase > 0) {             // A/B (QPX_TUNE_DEPHASE): see k_fwd_tile
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if ((hw >> 16) & 1)
-            for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     prefac_tile_body<NBN, kEq>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
 template <int NBN, bool kEq> int launch_prefac_tile(const PrefactorArgs<double>& a, size_t lds_bytes, void* stream)
@@ -233,40 +228,6 @@ template int launch_prefac_tile<4, false>(const PrefactorArgs<double>&, size_t, 
 template int launch_prefac_tile<7, false>(const PrefactorArgs<double>&, size_t, void*);
 template int launch_prefac_tile<4, true>(const PrefactorArgs<double>&, size_t, void*);
 template int launch_prefac_tile<7, true>(const PrefactorArgs<double>&, size_t, void*);
-#elif QPX_TU_KERNEL == 15
-// qpx_forward as ONE launch (round 5): pre_factor_kkt on the matrix cores (qpx_prefac.h) and the chain-wave loop
-// kernel (qpx_tile.h) back to back in the same workgroup -- no launch boundary, no chip-wide wait for the slowest
-// pre-factorisation before the first loop iteration, and the blob the loop's prologue reads is what this workgroup wrote
-// a moment ago (L2).  The blob is still written in full: the backward launch reads it.
-template <int NBN, int NS> __global__ __launch_bounds__(256, 2) void k_fwd_tile(FwdArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    double* lds = reinterpret_cast<double*>(qpx_smem);
-    if (a.dephase > 0) {
-        // A/B (QPX_TUNE_DEPHASE): the second workgroup of a CU (HW_ID.tg_id odd) starts a.dephase x ~8 k cycles late, so that
-        // the latency-bound phases of one QP sit beside the matrix streams of the other
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if ((hw >> 16) & 1)
-            for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    prefac_tile_body<NBN, false>(b, a.pre, (int)blockIdx.x, lds);
-    b.sync();                        // every store of the blob has left this CU ...
-    __threadfence();                 // ... and no stale line of it is read back
-    b.sync();
-    ipm_tile_body<NBN, 4, NS, true>(b, a.ipm, (int)blockIdx.x, lds);
-}
-template <int NBN, int NS> int launch_fwd_tile(const FwdArgs& a, size_t lds_bytes, void* stream)
-{
-    auto kern = k_fwd_tile<NBN, NS>;
-    static BigLdsFlags big_lds_enabled;
-    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.pre.B), dim3(256), lds_bytes, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
-}
-template int launch_fwd_tile<7, 2>(const FwdArgs&, size_t, void*);
-template int launch_fwd_tile<4, 1>(const FwdArgs&, size_t, void*);
 #elif QPX_TU_KERNEL == 10 || QPX_TU_KERNEL == 11
 // defined below, outside the launcher chain
 #elif QPX_TU_KERNEL == 9
@@ -280,12 +241,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ipm_tile(IpmArgs<double> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    if (a.dephase > 0) {             // A/B (QPX_TUNE_DEPHASE): see k_fwd_tile
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if ((hw >> 16) & 1)
-            for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     ipm_tile_body<NBL, NW, NS, CH>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
 }
 template <int NBL, int NW, int NS, bool CH> int launch_ipm_tile(const IpmArgs<double>& a, size_t lds_bytes, void* stream)
@@ -500,11 +455,17 @@ template <class T> __global__ __launch_bounds__(64 * kOuterWaves) void k_batch_o
 {
     __shared__ T lds[kOuterWaves * 256];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    batch_outer_body<T>(b, a, (int)blockIdx.x, lds);
+    batch_outer_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, lds);
+}
+template <class T> __global__ __launch_bounds__(256) void k_batch_outer_sum(OuterArgs<T> a)
+{
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    batch_outer_sum_body<T>(b, a, (int)blockIdx.x);
 }
 template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void* stream)
 {
-    hipLaunchKernelGGL(k_batch_outer<T>, dim3(tiles), dim3(64 * kOuterWaves), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_batch_outer<T>, dim3(tiles, a.chunks), dim3(64 * kOuterWaves), 0, (hipStream_t)stream, a);
+    if (a.chunks > 1) hipLaunchKernelGGL(k_batch_outer_sum<T>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
 template int launch_batch_outer<QPX_TU_REAL>(const OuterArgs<QPX_TU_REAL>&, int, void*);

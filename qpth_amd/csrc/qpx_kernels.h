@@ -315,7 +315,6 @@ template <class T> struct PrefactorArgs {
     // matrix-core form (qpx_prefac.h) only: which tiles of K (pf_k) and of R (pf_r) each of the four waves computes, bit
     // t = tile (i, j), t = i (i + 1) / 2 + j -- a greedy balance the host works out once per launch (prefac_deal)
     unsigned pf_k[4] = {0, 0, 0, 0}, pf_r[4] = {0, 0, 0, 0};
-    int dephase = 0;                      // A/B (qpx_set_tuning): start delay of a CU's second workgroup (matrix-core form)
 };
 
 template <class T> struct IpmArgs {
@@ -332,7 +331,6 @@ template <class T> struct IpmArgs {
     T* trace;                             // optional [maxIter][B][3]: pri_resid, dual_resid, mu
     int images;                           // blob family the factors were written in (fac_layout)
     int io32 = 0;                         // T = double only: every array but `fac` is float32 (QPX_F32_WIDE)
-    int dephase = 0;                      // A/B (qpx_set_tuning): start delay of a CU's second workgroup, units of ~8 k cycles (tile kernels)
 };
 
 template <class T> struct KktArgs {

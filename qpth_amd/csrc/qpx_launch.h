@@ -37,9 +37,6 @@ template <int NBL, int NW, bool kBw, bool CH = false> int launch_kkt_tile(const 
 template <class T, int NBL, int NS> int launch_ipm_grid8(const IpmArgs<T>& a, size_t lds_bytes, void* stream);   // 8x8 grid = one wave
 template <class T, int NBL, bool kBw> int launch_kkt_grid(const KktArgs<T>& a, size_t lds_bytes, void* stream);
 
-// qpx_forward as one launch: matrix-core pre-factorisation + chain-wave loop kernel in the same workgroup (f64, neq = 0)
-template <int NBN, int NS> int launch_fwd_tile(const FwdArgs& a, size_t lds_bytes, void* stream);
-
 // the finishing stage (qpx_polish): thread grid (any dtype) and matrix-core tiles (f64)
 template <class T, int NBL> int launch_polish_grid(const PolishArgs<T>& a, size_t lds_bytes, void* stream);
 template <int NBL, int NW, bool CH> int launch_polish_tile(const PolishArgs<double>& a, size_t lds_bytes, void* stream);

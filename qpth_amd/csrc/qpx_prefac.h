@@ -523,11 +523,4 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
     if (b.tid == 0) a.status[qp] = 0;
 }
 
-// qpx_forward as one launch (k_fwd_tile): the argument blocks of both bodies
-struct FwdArgs {
-    PrefactorArgs<double> pre;
-    IpmArgs<double> ipm;
-    int dephase;
-};
-
 }  // namespace qpx

@@ -298,19 +298,6 @@ template <int NBN, bool kEq> int launch_prefac_tile(const PrefactorArgs<double>&
     }
     return QPX_OK;
 }
-template <int NBN, int NS> int launch_fwd_tile(const FwdArgs& a, size_t lds_bytes, void*)
-{
-    for (int qp = 0; qp < a.pre.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
-        double* base = reinterpret_cast<double*>(lds.data());
-        run_block(256, [&](const Block& b) {
-            prefac_tile_body<NBN, false>(b, a.pre, qp, base);
-            b.sync();
-            ipm_tile_body<NBN, 4, NS, true>(b, a.ipm, qp, base);
-        });
-    }
-    return QPX_OK;
-}
 template <class T, int NBL, int NS> int launch_ipm_grid(const IpmArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
@@ -461,10 +448,13 @@ template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void*)
 
 template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void*)
 {
-    for (int t = 0; t < tiles; ++t) {
-        std::vector<T> lds((size_t)kOuterWaves * 256);
-        run_block(64 * kOuterWaves, [&](const Block& b) { batch_outer_body<T>(b, a, t, lds.data()); });
-    }
+    for (int ch = 0; ch < a.chunks; ++ch)
+        for (int t = 0; t < tiles; ++t) {
+            std::vector<T> lds((size_t)kOuterWaves * 256);
+            run_block(64 * kOuterWaves, [&](const Block& b) { batch_outer_body<T>(b, a, t, ch, lds.data()); });
+        }
+    if (a.chunks > 1)
+        for (int t = 0; t < tiles; ++t) run_block(256, [&](const Block& b) { batch_outer_sum_body<T>(b, a, t); });
     return QPX_OK;
 }
 

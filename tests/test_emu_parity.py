@@ -400,39 +400,6 @@ def test_chain_wave_form(shape):
             assert np.abs(mine - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("shape", [(2, 100, 100), (2, 97, 110), (3, 64, 64), (2, 50, 49)])
-def test_forward_as_one_launch_equals_the_two_launches(shape):
-    """qpx_forward as ONE launch (k_fwd_tile, QPX_TUNE_FUSED_FORWARD = 2: the matrix-core pre-factorisation and the
-    chain-wave loop kernel back to back in one workgroup) against qpx_pre_factor + qpx_ipm on the same data: same blob,
-    same iterates, same iteration counts; and the result against the oracle."""
-    from emu.harness import emu_lib
-    from qpth_amd import _lib
-    B, n, m = shape
-    Q, p, G, h, A, b = problems.prof_qp(B, n, m, 0, seed=21)
-    tQ, tp, tG, th = [torch.tensor(x) for x in (Q, p, G, h)]
-    lib = emu_lib()
-    elems = lib.factor_elems(_lib.QPX_F64, n, m, 0)
-    out = {}
-    for fused in (1, 2):
-        blob = torch.zeros(B * elems, dtype=torch.float64)
-        st = torch.zeros(B, dtype=torch.int32)
-        z, lam, sl = torch.zeros(B, n, dtype=torch.float64), torch.zeros(B, m, dtype=torch.float64), torch.zeros(B, m, dtype=torch.float64)
-        it, br = torch.zeros(B, dtype=torch.int32), torch.zeros(B, dtype=torch.float64)
-        old = lib.dll.qpx_set_tuning(_lib.TUNE_FUSED_FORWARD, fused)
-        try:
-            assert lib.dll.qpx_forward_is_one_launch(_lib.QPX_F64, B, n, m, 0) == (1 if fused == 2 else 0)
-            with emulated(256):
-                lib.forward(B, n, m, 0, tQ, tp, tG, th, None, None, blob, 1e-12, 20, 3, _lib.STALL_FLOOR, z, None, lam, sl, it, st, br)
-        finally:
-            lib.dll.qpx_set_tuning(_lib.TUNE_FUSED_FORWARD, old)
-        out[fused] = (blob, z, lam, sl, it, st, br)
-    for a_, b_ in zip(out[1], out[2]):
-        assert torch.equal(a_, b_)
-    xr = orc.OracleQP(Q, p, G, h, A, b).forward(per_qp=True, stall_policy=2)[0]
-    assert rel_err(out[2][1].numpy(), xr).max() < TOL
-    assert lib.dll.qpx_set_tuning(99, 0) < 0 and lib.dll.qpx_set_tuning(_lib.TUNE_DEPHASE, -1) < 0      # unknown key / negative value: refused
-
-
 @pytest.mark.parametrize("variant", LOOP_FORMS)
 @pytest.mark.parametrize("name", ["c1_b8_n10_m5_f64", "c3s_b4_n20_m10_q4_f64"])
 def test_every_loop_kernel_form_against_the_reference(variant, name):
@@ -755,6 +722,40 @@ def _kkt_residual(Q, G, A, d, rx, rs, rz, ry, dx, ds, dz, dy):
     e3 = np.einsum('bmi,bi->bm', G, dx) + ds + rz
     e4 = np.einsum('bqi,bi->bq', A, dx) + ry
     return np.sqrt((e1 ** 2).sum(1) + (e2 ** 2).sum(1) + (e3 ** 2).sum(1) + (e4 ** 2).sum(1))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("shape", [(600, 10, 37), (1100, 33, 20), (40, 5, 5)])
+def test_batch_contraction_in_two_stages(shape, dtype):
+    """qpx_batch_outer (qp.py:159-177 for a shared parameter): long batches are contracted in TWO stages when the caller
+    brings the workspace -- partial tiles per chunk of whole 256-QP trips, then their sum in chunk order -- and by one
+    workgroup per tile otherwise; both against the plain sum of outer products, and the two-stage result twice
+    (fixed order: bit-identical)."""
+    import ctypes
+    from emu.harness import emu_lib
+    from qpth_amd import _lib
+    B, r, c = shape
+    g = torch.Generator().manual_seed(B + r)
+    u, w = torch.randn(B, r, dtype=dtype, generator=g), torch.randn(B, r, dtype=dtype, generator=g)
+    v, x = torch.randn(B, c, dtype=dtype, generator=g), torch.randn(B, c, dtype=dtype, generator=g)
+    ref = 0.5 / B * (u.double().t() @ v.double() + w.double().t() @ x.double())
+    lib = emu_lib()
+    code = _lib.QPX_F64 if dtype == torch.float64 else _lib.QPX_F32
+    need = int(lib.dll.qpx_batch_outer_workspace_elems(code, B, r, c))
+    assert (need > 0) == (B > 256)
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    outs = []
+    with emulated(256):
+        for rep in range(2):
+            out = torch.full((r, c), float("nan"), dtype=dtype)
+            lib.batch_outer(u, v, w, x, 0.5, out)                       # two stages when need > 0
+            outs.append(out)
+        one = torch.full((r, c), float("nan"), dtype=dtype)
+        lib.check(lib.dll.qpx_batch_outer(code, B, r, c, u.data_ptr(), v.data_ptr(), w.data_ptr(), x.data_ptr(), 0.5,
+                                          one.data_ptr(), None, 0, None))                 # no workspace: one stage
+    assert torch.equal(outs[0], outs[1])
+    for o in (outs[0], one):
+        assert (o.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
 def test_iterative_refinement_of_the_kkt_solve():

@@ -416,36 +416,35 @@ def test_large_qps_with_equality_constraints(dev, B, n, m, q, seed):
         assert np.abs(a_ - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max()), k
 
 
-@pytest.mark.parametrize("shape", [(512, 100, 100), (640, 64, 64), (96, 97, 110)])
-def test_forward_as_one_launch_equals_the_two_launches(dev, shape):
-    """qpx_forward as ONE launch (k_fwd_tile, QPX_TUNE_FUSED_FORWARD = 2) against qpx_pre_factor + qpx_ipm on the same data
-    through the C ABI: same blob, same iterates, same iteration counts (1e-12: the two forms are compiled in different
-    translation units); with the CU's second workgroup started late (QPX_TUNE_DEPHASE) nothing changes either."""
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("shape", [(8192, 10, 100), (8192, 100, 100), (700, 64, 64), (100, 3, 3)])
+def test_batch_contraction_in_two_stages(dev, shape, dtype):
+    """qpx_batch_outer at the shapes of shared-parameter gradients (dA 10 x 100 and dQ 100 x 100 at one GPU's share of C5,
+    qp.py:159-177): two stages with the workspace (partial tiles per batch chunk, summed in chunk order -- twice: the same
+    bits) and one stage without it, both against the float64 sum of outer products."""
     from qpth_amd import _lib
-    B, n, m = shape
-    Q, p, G, h, A, b = problems.prof_qp(B, n, m, 0, seed=21)
-    tQ, tp, tG, th = to_dev([Q, p, G, h], dev, grad=False)
+    B, r, c = shape
+    g = torch.Generator().manual_seed(B + r)
+    u, w = [torch.randn(B, r, dtype=dtype, generator=g).to(dev) for _ in range(2)]
+    v, x = [torch.randn(B, c, dtype=dtype, generator=g).to(dev) for _ in range(2)]
+    ref = (0.5 / B * (u.double().t() @ v.double() + w.double().t() @ x.double())).cpu()
     lib = _lib.hip()
-    elems = lib.factor_elems(_lib.QPX_F64, n, m, 0)
-    out = {}
-    for key, (fused, dephase) in {"two": (1, 0), "one": (2, 0), "one_late": (2, 3), "two_late": (1, 2)}.items():
-        blob = torch.zeros(B * elems, dtype=torch.float64, device=dev)
-        st = torch.zeros(B, dtype=torch.int32, device=dev)
-        z, lam, sl = [torch.zeros(B, k, dtype=torch.float64, device=dev) for k in (n, m, m)]
-        it, br = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.float64, device=dev)
-        o1, o2 = lib.dll.qpx_set_tuning(_lib.TUNE_FUSED_FORWARD, fused), lib.dll.qpx_set_tuning(_lib.TUNE_DEPHASE, dephase)
-        try:
-            assert lib.dll.qpx_forward_is_one_launch(_lib.QPX_F64, B, n, m, 0) == (1 if fused == 2 else 0)
-            lib.forward(B, n, m, 0, tQ, tp, tG, th, None, None, blob, 1e-12, 20, 3, _lib.STALL_FLOOR, z, None, lam, sl, it, st, br)
-            torch.cuda.synchronize()
-        finally:
-            lib.dll.qpx_set_tuning(_lib.TUNE_FUSED_FORWARD, o1)
-            lib.dll.qpx_set_tuning(_lib.TUNE_DEPHASE, o2)
-        out[key] = (blob.cpu().numpy(), z.cpu().numpy(), lam.cpu().numpy(), sl.cpu().numpy(), it.cpu().numpy(), st.cpu().numpy())
-    for key in ("one", "one_late", "two_late"):
-        for a_, r_ in zip(out[key][:4], out["two"][:4]):
-            assert np.abs(a_ - r_).max() <= 1e-12 * max(1.0, np.abs(r_).max()), key
-        assert (out[key][4] == out["two"][4]).all() and (out[key][5] == out["two"][5]).all(), key
+    code = _lib.QPX_F64 if dtype == torch.float64 else _lib.QPX_F32
+    need = int(lib.dll.qpx_batch_outer_workspace_elems(code, B, r, c))
+    assert (need > 0) == (B > 256)
+    outs = []
+    for rep in range(2):
+        out = torch.full((r, c), float("nan"), dtype=dtype, device=dev)
+        lib.batch_outer(u, v, w, x, 0.5, out)
+        outs.append(out.cpu())
+    one = torch.full((r, c), float("nan"), dtype=dtype, device=dev)
+    lib.check(lib.dll.qpx_batch_outer(code, B, r, c, u.data_ptr(), v.data_ptr(), w.data_ptr(), x.data_ptr(), 0.5,
+                                      one.data_ptr(), None, 0, torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    for o in (outs[0], one.cpu()):
+        assert (o.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
 def test_large_qp_accuracy_options_against_the_oracle(dev):
