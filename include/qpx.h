@@ -27,7 +27,7 @@
  *     factorisations from qpx_pre_factor to qpx_ipm / qpx_factor_solve_kkt / qpx_backward
  *     (what the reference stashes on ctx as Q_LU, S_LU, R; qpth/qp.py:93).  Consumers take
  *     its batch stride `sfac` in elements: qpx_factor_elems(dtype,n,m,q), or 0 when Q, G, A are
- *     shared by the whole batch and were factored once with B = 1 (only if qpx_fits_lds()).
+ *     shared by the whole batch and were factored once with B = 1 (only if qpx_can_share_factors()).
  *   - `status`: int32[B], per-QP bit mask of QPX_ST_* written on the device; the functions
  *     themselves return 0 or a negative QPX_ERR_* launch/argument error and never throw.
  *   - Semantics of the IPM loop are those of the reference for a batch of one per QP; see
@@ -85,29 +85,26 @@ const char* qpx_strerror(int code);
 /* elements (of dtype) of factor storage per QP (C2, f64: 27 100 = 217 KB; B = 65536, n = m = 64: 5.5 GB) */
 size_t qpx_factor_elems(int dtype, int n, int m, int q);
 
-/* largest max(n,m,q) this build can solve; whether (n,m,q) runs with LDS-resident matrices */
+/* largest max(n,m,q) this build can solve */
 int qpx_max_dim(void);
 /* QPX_OK if (dtype, n, m, q) is served under the calling thread's knob, else the QPX_ERR_* the entry points would
  * return (QPX_F32_WIDE: QPX_ERR_UNSUPPORTED outside the thread-grid / tile kernels' sizes) */
 int qpx_supported(int dtype, int n, int m, int q);
 /* v6: which kernel family serves (dtype, n, m, q) under the calling thread's knob (or a negative QPX_ERR_*):
- * the round-1 workgroup kernels, the thread-grid kernels, the float64 matrix-core tile kernels (nineq <= 112,
- * nz+neq+nineq <= 208), or the large-QP family (multi-kernel blocked Cholesky / GEMM path).  The host mirror uses it
- * to decide where float32 tensors run in float64 arithmetic (QPX_F32_WIDE: the last two). */
-enum { QPX_FAMILY_WORKGROUP = 0, QPX_FAMILY_GRID = 1, QPX_FAMILY_TILE = 2, QPX_FAMILY_BIG = 3 };
+ * the thread-grid kernels, the float64 matrix-core tile kernels (nineq <= 112, nz+neq+nineq <= 208), or the large-QP
+ * family (multi-kernel blocked Cholesky / GEMM path).  The host mirror uses it to decide where float32 tensors run in
+ * float64 arithmetic (QPX_F32_WIDE: the last two).  (0 was the family of the round-1 workgroup kernels, deleted in v7.) */
+enum { QPX_FAMILY_GRID = 1, QPX_FAMILY_TILE = 2, QPX_FAMILY_BIG = 3 };
 int qpx_kernel_family(int dtype, int n, int m, int q);
 /* v5: 1 if qpx_factor_solve_kkt / qpx_backward implement refine > 0 for this size and dtype (else they return
  * QPX_ERR_UNSUPPORTED when asked to): the in-kernel iterative refinement of KKTSolvers.IR_UNOPT, batch.py:244-270. */
 int qpx_refine_supported(int dtype, int n, int m, int q);
-int qpx_fits_lds(int dtype, int n, int m, int q);
 
 /* tuning/A-B knob (per host thread): which kernel family runs.  0 (default) = automatic: the thread-grid /
  * matrix-core kernels (sweep pre-factorisation, register-resident LDL^T with in-place inverse factor)
- * whenever nz+neq+nineq <= 208, else one 256-thread workgroup per QP with the matrices in LDS
- * (sizes whose matrices do not fit in LDS -- BASELINE.json configs[3], nz = nineq = 500 -- run
- * through the large-QP family: batched multi-kernel blocked Cholesky / MFMA GEMM path, qpx_big.h; equality
- * constraints included since v6);
- * 1 = always the workgroup kernels; 3 = always the large-QP family.
+ * whenever nz+neq+nineq <= 208, else the large-QP family (batched multi-kernel blocked Cholesky / MFMA GEMM path,
+ * qpx_big.h -- BASELINE.json configs[3], nz = nineq = 500; equality constraints included since v6);
+ * 3 = always the large-QP family.  (1 selected the round-1 workgroup kernels until v7: deleted, the value now means 0.)
  * Adding 256 / 512 / 1024 forces the 16x16-thread grid / the 8x8-thread grid / the matrix-core tile form
  * (f64, nineq <= 112) of the loop kernel, adding 2048 / 4096 / 8192 fixes the tile form's waves per QP
  * at 1 / 2 / 4 (four waves at 4 or 7 tile rows = the chain-wave form, which is the default there); by default the
@@ -130,7 +127,8 @@ int qpx_set_ipm_variant(int variant);
 int qpx_get_ipm_variant(void);      /* the calling thread's current value */
 
 /* May a batch whose Q, G, A are shared be served by ONE factor blob (qpx_pre_factor with B = 1, consumers
- * with sfac = 0)?  Always for the thread-grid / tile kernels; for the workgroup kernels only if qpx_fits_lds. */
+ * with sfac = 0)?  Yes for the thread-grid / tile kernels, which only read the blob; no for the large-QP family, which keeps
+ * per-QP work matrices in it. */
 int qpx_can_share_factors(int dtype, int n, int m, int q);
 
 /* Measurement hook (bench.py): re-issues the largest GEMM of the large-QP pre-factorisation, R = Zt Zt^T, on the
@@ -218,6 +216,12 @@ int qpx_batch_outer(int dtype, int B, int r, int c, const void* u, const void* v
  * order: bit-reproducible, no atomics).  NULL / too small / 0 elements needed: one workgroup per 16 x 16 tile of `out`
  * walks the whole batch, as before -- the same result up to the order of the additions. */
 size_t qpx_batch_outer_workspace_elems(int dtype, int B, int r, int c);
+
+/* v7: x = M^-1 r for B general k x k systems (Gaussian elimination with partial pivoting, one workgroup each).  M (B,k,k)
+ * is destroyed, rhs (B,k) is overwritten by the solution; a singular M ORs QPX_ST_KKT_BREAKDOWN into status[b] (may be
+ * NULL) and returns NaNs.  The host mirror's factor_solve_kkt_reg (qpth/solvers/pdipm/batch.py:273-310) with equality
+ * constraints uses it for the neq x neq correction of the regularised (y, y) block. */
+int qpx_dense_solve(int dtype, int B, int k, void* M, void* rhs, int32_t* status, qpx_stream_t stream);
 
 #ifdef __cplusplus
 }

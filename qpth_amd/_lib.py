@@ -20,7 +20,7 @@ HIP_SO = os.path.join(_HERE, "libqpx_hip.so")
 QPX_F32, QPX_F64, QPX_F32_WIDE = 0, 1, 2      # QPX_F32_WIDE: float32 arrays, float64 factors and arithmetic (include/qpx.h)
 ST_Q_NOT_SPD, ST_A_RANK, ST_KKT_BREAKDOWN, ST_INACCURATE, ST_MAXITER, ST_NONFINITE = 1, 2, 4, 8, 16, 32
 STALL_OFF, STALL_REFERENCE, STALL_FLOOR = 0, 1, 2
-FAMILY_WORKGROUP, FAMILY_GRID, FAMILY_TILE, FAMILY_BIG = 0, 1, 2, 3
+FAMILY_GRID, FAMILY_TILE, FAMILY_BIG = 1, 2, 3
 
 _vp, _i, _i64, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 
@@ -33,7 +33,6 @@ _SIGNATURES = {
     "qpx_supported": (_i, [_i, _i, _i, _i]),
     "qpx_kernel_family": (_i, [_i, _i, _i, _i]),
     "qpx_refine_supported": (_i, [_i, _i, _i, _i]),
-    "qpx_fits_lds": (_i, [_i, _i, _i, _i]),
     "qpx_set_ipm_variant": (_i, [_i]),
     "qpx_get_ipm_variant": (_i, []),
     "qpx_can_share_factors": (_i, [_i, _i, _i, _i]),
@@ -52,6 +51,7 @@ _SIGNATURES = {
                         _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qpx_batch_outer": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp, ctypes.c_size_t, _vp]),
     "qpx_batch_outer_workspace_elems": (ctypes.c_size_t, [_i, _i, _i, _i]),
+    "qpx_dense_solve": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
 }
 ABI_SYMBOLS = tuple(_SIGNATURES)
 
@@ -196,6 +196,14 @@ class QpxLib:
         ws = torch.empty(need, dtype=out.dtype, device=out.device) if need else None
         self.check(self.dll.qpx_batch_outer(code, B, r, c, _ptr(u), _ptr(v), _ptr(w), _ptr(x),
                                             float(scale), _ptr(out), _ptr(ws), need, _stream(out)))
+
+
+    # -- the neq x neq correction of factor_solve_kkt_reg (batch.py:273-310): x = M^-1 r, M destroyed, r overwritten
+    def dense_solve(self, M, rhs, status=None):
+        B, k = rhs.shape
+        assert M.shape == (B, k, k) and M.is_contiguous() and rhs.is_contiguous() and M.dtype == rhs.dtype
+        self.check(self.dll.qpx_dense_solve(_dtype_code(rhs), B, k, _ptr(M), _ptr(rhs), _ptr(status), _stream(rhs)))
+        return rhs
 
 
 _HIP = None

@@ -36,6 +36,7 @@ constexpr int kBB = 64;          // block order
 constexpr int kBE = kBB * kBB;   // elements of a block
 QPX_LAYOUT_HD size_t big_blk(int ld, int rb, int cb) { return ((size_t)rb * (ld / kBB) + cb) * kBE; }
 QPX_LAYOUT_HD size_t big_at(int ld, int i, int j) { return big_blk(ld, i >> 6, j >> 6) + (size_t)(i & 63) * kBB + (j & 63); }
+constexpr int kBigPolVecs = 32;      // element-sized vectors of the finishing stage's region (BigLayout::pol)
 constexpr int kMaxSide = 3;          // side streams the host may spread the parts of a batch over (qpx_api.inc: big_split)
 constexpr int kBL = kBB + 2;     // LDS row stride of a staged block (elements): 2-way bank conflicts at most
 QPX_LAYOUT_HD int big_pad(int x) { return (x + kBB - 1) / kBB * kBB; }
@@ -57,7 +58,7 @@ enum BigCtrl { bcStop = 0, bcNnot, bcFloor, bcSt, bcIters, bcFail };
 // The blob keeps Yt (right behind Zt, same row length: the solve with Lq^-T runs once over the stacked rows of G and A),
 // L11 with its diagonal-block inverses, and Vh; Us is the scratch of the pre-factorisation (Vh L11^-1).
 struct BigLayout {
-    size_t Lq, Wq, Zt, Yt, R, T, Wt, S11, Wy, Vh, Us, vec, scal, ctrl, total;
+    size_t Lq, Wq, Zt, Yt, R, T, Wt, S11, Wy, Vh, Us, vec, scal, ctrl, pol, total;
     int NP, MP, QP, VP;
     QPX_LAYOUT_HD size_t v(int i) const { return vec + (size_t)i * VP; }
 };
@@ -80,6 +81,9 @@ QPX_LAYOUT_HD BigLayout big_layout(int n, int m, int q = 0)
     L.vec = o; o += (size_t)bvCount * L.VP;
     L.scal = o; o += 16;
     L.ctrl = o; o += 16;
+    // the finishing stage (qpx_big_polish.h): iterate and best iterate in DOUBLE whatever the element type -- room for 16
+    // vectors of VP doubles when the elements are floats (32 of them when they are doubles)
+    L.pol = o; o += (size_t)kBigPolVecs * L.VP;
     L.total = o;
     return L;
 }

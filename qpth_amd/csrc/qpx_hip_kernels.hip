@@ -4,8 +4,8 @@
 // (dynamic, up to the full 160 KiB) for the whole kernel, or in the HBM factor blob when they
 // do not fit.  Kernels are stream-ordered, allocate nothing and never synchronise the host.
 //
-// Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 1 = prefactor, 2 = ipm (workgroup per QP),
-// 3 = kkt/backward, 5 = sweep pre-factorisation (16x16 thread grid),
+// Compiled once per (QPX_TU_KERNEL, QPX_TU_REAL): 5 = sweep pre-factorisation (16x16 thread grid),
+// (1, 2, 3 were the round-1 workgroup kernels, deleted in round 5)
 // 6 = ipm (thread grid), 7 = kkt/backward (thread grid), 8 = ipm (8x8 thread grid = one wave), 9 = ipm (matrix-core tiles, f64 only),
 // 10 = batch-mean outer products of shared-parameter gradients, 11 = the large-QP family (qpx_big.h),
 // 13 = the finishing stage on matrix-core tiles (f64 only; its thread-grid form lives in 7), 14 = pre_factor_kkt on matrix-core tiles (f64 only).
@@ -18,7 +18,7 @@
 #include "qpx_launch.h"
 
 #ifndef QPX_TU_KERNEL
-#error "QPX_TU_KERNEL (1|2|3) and QPX_TU_REAL (float|double) must be defined"
+#error "QPX_TU_KERNEL and QPX_TU_REAL (float|double) must be defined"
 #endif
 
 namespace qpx {
@@ -41,65 +41,7 @@ template <class K> static int allow_big_lds(K kernel, size_t bytes, BigLdsFlags&
     return QPX_OK;
 }
 
-#if QPX_TU_KERNEL == 1
-template <class T, int NS, bool kLds>
-__global__ __launch_bounds__(kThreads) void k_prefactor(PrefactorArgs<T> a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    prefactor_body<T, NS, kLds>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
-}
-template <class T, int NS, bool kLds>
-int launch_prefactor(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream)
-{
-    auto kern = k_prefactor<T, NS, kLds>;
-    static BigLdsFlags big_lds_enabled;   // one set of flags per kernel instantiation
-    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
-}
-#define QPX_INST(NS, L) \
-    template int launch_prefactor<QPX_TU_REAL, NS, L>(const PrefactorArgs<QPX_TU_REAL>&, size_t, void*);
-#elif QPX_TU_KERNEL == 2
-template <class T, int NS, bool kLds>
-__global__ __launch_bounds__(kThreads) void k_ipm(IpmArgs<T> a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    ipm_body<T, NS, kLds>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
-}
-template <class T, int NS, bool kLds>
-int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void* stream)
-{
-    auto kern = k_ipm<T, NS, kLds>;
-    static BigLdsFlags big_lds_enabled;   // one set of flags per kernel instantiation
-    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
-}
-#define QPX_INST(NS, L) \
-    template int launch_ipm<QPX_TU_REAL, NS, L>(const IpmArgs<QPX_TU_REAL>&, size_t, void*);
-#elif QPX_TU_KERNEL == 3
-template <class T, int NS, bool kLds, bool kBw>
-__global__ __launch_bounds__(kThreads) void k_kkt(KktArgs<T> a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
-    const Block b{(int)threadIdx.x, (int)blockDim.x};
-    kkt_body<T, NS, kLds, kBw>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
-}
-template <class T, int NS, bool kLds, bool kBw>
-int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream)
-{
-    auto kern = k_kkt<T, NS, kLds, kBw>;
-    static BigLdsFlags big_lds_enabled;   // one set of flags per kernel instantiation
-    if (allow_big_lds(kern, lds_bytes, big_lds_enabled)) return QPX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
-}
-#define QPX_INST(NS, L)                                                                              \
-    template int launch_kkt<QPX_TU_REAL, NS, L, false>(const KktArgs<QPX_TU_REAL>&, size_t, void*); \
-    template int launch_kkt<QPX_TU_REAL, NS, L, true>(const KktArgs<QPX_TU_REAL>&, size_t, void*);
-#elif QPX_TU_KERNEL == 5
+#if QPX_TU_KERNEL == 5
 // (at least two workgroups per CU -- <= 256 registers -- at every size: the largest instantiation holds 91 matrix entries per thread)
 template <class T, int NBL> __global__ __launch_bounds__(256, 2) void k_sweep(PrefactorArgs<T> a)
 {
@@ -373,6 +315,12 @@ template <class T, int NS> __global__ __launch_bounds__(256) void k_big_diag(Big
     const Block b{(int)threadIdx.x, (int)blockDim.x};
     big_diag_body<T, NS>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
 }
+template <class T> __global__ __launch_bounds__(64 * kBigPolWaves) void k_big_polish(BigPolishArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    big_polish_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<double*>(qpx_smem));
+}
 template <class K, class A> static int big_launch(K kern, const A& a, int gx, int gy, int threads, size_t lds, void* stream, BigLdsFlags& big_ok)
 {
     if (allow_big_lds(kern, lds, big_ok)) return QPX_ERR_LAUNCH;
@@ -442,7 +390,14 @@ template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* s)
     default: return big_launch(k_big_diag<T, 8>, a, a.p.B, 1, 256, lds, s, f);
     }
 }
+template <class T> int launch_big_polish(const BigPolishArgs<T>& a, void* s)
+{
+    static BigLdsFlags f;
+    const BigLayout L = big_layout(a.n, a.m, a.q);
+    return big_launch(k_big_polish<T>, a, a.B, 1, 64 * kBigPolWaves, big_polish_lds_doubles(L.VP) * sizeof(double), s, f);
+}
 #define QPX_INSTB(NAME, ARGS) template int NAME<QPX_TU_REAL>(const ARGS<QPX_TU_REAL>&, void*);
+QPX_INSTB(launch_big_polish, BigPolishArgs)
 QPX_INSTB(launch_big_solve, BigSolveArgs) QPX_INSTB(launch_big_diag, BigDiagArgs)
 template int launch_big_pack<QPX_TU_REAL>(const BigPackArgs<QPX_TU_REAL>&, int, void*);
 template int launch_big_kkt<QPX_TU_REAL>(const BigKktArgs<QPX_TU_REAL>&, int, void*);
@@ -469,11 +424,18 @@ template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void
     return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
 }
 template int launch_batch_outer<QPX_TU_REAL>(const OuterArgs<QPX_TU_REAL>&, int, void*);
-#endif
-
-#if QPX_TU_KERNEL >= 1 && QPX_TU_KERNEL <= 3
-QPX_INST(1, true) QPX_INST(1, false) QPX_INST(2, true) QPX_INST(2, false)
-QPX_INST(4, true) QPX_INST(4, false) QPX_INST(8, true) QPX_INST(8, false)
+template <class T> __global__ __launch_bounds__(256) void k_dense_solve(DenseSolveArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
+    const Block b{(int)threadIdx.x, (int)blockDim.x};
+    dense_solve_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+}
+template <class T> int launch_dense_solve(const DenseSolveArgs<T>& a, void* stream)
+{
+    hipLaunchKernelGGL(k_dense_solve<T>, dim3(a.B), dim3(256), dense_solve_lds_elems(a.k) * sizeof(T), (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? QPX_OK : QPX_ERR_LAUNCH;
+}
+template int launch_dense_solve<QPX_TU_REAL>(const DenseSolveArgs<QPX_TU_REAL>&, void*);
 #endif
 
 }  // namespace qpx

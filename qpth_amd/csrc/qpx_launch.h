@@ -11,22 +11,14 @@
 #include "qpx_prefac.h"
 #include "qpx_reduce.h"
 #include "qpx_big.h"
+#include "qpx_big_polish.h"
 
 namespace qpx {
 
 template <int V> using Int = std::integral_constant<int, V>;
 template <bool V> using Bool = std::integral_constant<bool, V>;
 
-constexpr int kThreads = 256;   // one workgroup = 4 wave64 per QP
-
 inline size_t lds_budget_bytes() { return kMaxLdsBytes; }
-
-template <class T, int NS, bool kLds>
-int launch_prefactor(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream);
-template <class T, int NS, bool kLds>
-int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void* stream);
-template <class T, int NS, bool kLds, bool kBw>
-int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void* stream);
 
 // thread-grid kernels (qpx_grid.h), 16x16 threads per QP, format-3 blob
 template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void* stream);
@@ -43,6 +35,7 @@ template <int NBL, int NW, bool CH> int launch_polish_tile(const PolishArgs<doub
 
 // batch-mean outer products of shared-parameter gradients (qpx_reduce.h): one workgroup of 16 waves per output tile
 template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void* stream);
+template <class T> int launch_dense_solve(const DenseSolveArgs<T>& a, void* stream);      // one general k x k system per workgroup (factor_solve_kkt_reg)
 
 // the large-QP family (qpx_big.h): every launch covers the batch; gy = workgroups per QP
 template <class T> int launch_big_pack(const BigPackArgs<T>& a, int gy, void* stream);
@@ -55,6 +48,7 @@ template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* stre
 template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* stream);
 template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* stream);
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* stream);
+template <class T> int launch_big_polish(const BigPolishArgs<T>& a, void* stream);      // the finishing stage (qpx_big_polish.h)
 // Side streams for the parts of a batch the large-QP family works on concurrently (qpx_api.inc: big_split).
 // stream_fork: side[0 .. nside) = streams of the calling host thread's pool, made to wait (event) for everything
 // enqueued on `caller` so far; stream_join: `caller` waits (events) for everything enqueued on them.  Neither

@@ -20,20 +20,10 @@
 //            bit 4: Rm  16x16 tiles in the C/D layout of v_mfma_f64_16x16x4 (tile_image_index)
 //   (f64 with m <= 112: Rm only; otherwise Rg + Rw).
 //
-// (b) workgroup kernels (qpx_kernels.h), any size up to 512 (`images` == 0): un-pivoted Cholesky
-//     factors (the reference's own GPU branch is un-pivoted, batch.py:8-20):
+// (b) the large-QP family (qpx_big.h), every larger size up to 512 per dimension (`images` == 8): BigLayout there --
+//     Cholesky factors and the projected Zt in 64 x 64 blocks, the loop's vectors, the finishing stage's iterates.
 //
-//   L      n(n+1)/2   Cholesky factor of Q, packed lower, row-major        (replaces Q_LU)
-//   dinvL  n          1 / L_kk
-//   Zp     n x m      P L^-1 G^T, P = projector onto null(A L^-T) (= L^-1 G^T when neq = 0)
-//   R      m(m+1)/2   Zp^T Zp, packed lower
-//   Yh     n x q      L^-1 A^T L11^-T (orthonormal columns)
-//   V      q x m      Yh^T L^-1 G^T
-//   L11    q(q+1)/2   Cholesky factor of A Q^-1 A^T, packed lower          (replaces S_LU[:q,:q])
-//   dinv11 q
-//   r1     m          R 1
-//   scal   4 (+8)
-//   T      m(m+1)/2   scratch: Cholesky factor of R + diag(1/d) when it does not fit in LDS
+// (Until round 5 a third family held the packed Cholesky factors of the round-1 workgroup kernels, `images` == 0.)
 #pragma once
 #include <cstddef>
 
@@ -104,13 +94,10 @@ QPX_LAYOUT_HD int sweep_nb(int ord)
 }
 
 struct FacLayout {
-    // family (b)
-    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, T;
-    // family (a)
     size_t Kneg, MT, NTn, W, S11i, Rg, Rw, Rm;
     size_t scal, prof;
     size_t total;
-    int images;   // 0: family (b); else bit mask of the R images present (1 Rg, 2 Rw, 4 Rm)
+    int images;   // bit mask of the R images present (1 Rg, 2 Rw, 4 Rm)
     int nbw;      // 8x8-grid blocks of 8 for m (0 = n/a)
     int nbg;      // grid blocks of 16 for m
     int nba;      // grid blocks of 16 for the augmented order n+q+m (0 = family (a) unavailable)
@@ -125,38 +112,21 @@ QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q, int images)
     FacLayout f;
     size_t o = 0;
     f.images = images;
-    f.L = f.dinvL = f.Zp = f.R = f.Yh = f.V = f.L11 = f.dinv11 = f.r1 = f.T = 0;
     f.Kneg = f.MT = f.NTn = f.W = f.S11i = f.Rg = f.Rw = f.Rm = 0;
-    f.nbw = f.nbg = f.nba = f.nbt = 0;
-    if (images == 0) {
-        f.L = o;      o += align4(tri((size_t)n));
-        f.dinvL = o;  o += align4(n);
-        f.Zp = o;     o += align4((size_t)n * m);
-        f.R = o;      o += align4(tri((size_t)m));
-        f.Yh = o;     o += align4((size_t)n * q);
-        f.V = o;      o += align4((size_t)q * m);
-        f.L11 = o;    o += align4(tri((size_t)q));
-        f.dinv11 = o; o += align4(q);
-        f.r1 = o;     o += align4(m);
-        f.scal = o;   o += 4;
-        f.prof = o;   o += 8;
-        f.T = o;      o += align4(tri((size_t)m));
-    } else {
-        f.nba = grid_nb(n + q + m);
-        f.nbg = grid_nb(m);
-        f.nbw = wave_nb(m);
-        f.nbt = tile_nb(m);
-        f.Kneg = o; o += align4((size_t)n * n);
-        f.MT = o;   o += align4((size_t)n * m);
-        f.NTn = o;  o += align4((size_t)q * n);
-        f.W = o;    o += align4((size_t)m * q);
-        f.S11i = o; o += align4((size_t)q * q);
-        f.scal = o; o += 4;
-        f.prof = o; o += 8;
-        f.Rg = o;   if (images & 1) o += (size_t)(f.nbg * (f.nbg + 1) / 2) * 256;
-        f.Rw = o;   if ((images & 2) && f.nbw > 0) o += (size_t)(f.nbw * (f.nbw + 1) / 2) * 64;
-        f.Rm = o;   if ((images & 4) && f.nbt > 0) o += tile_image_elems(f.nbt);
-    }
+    f.nba = grid_nb(n + q + m);
+    f.nbg = grid_nb(m);
+    f.nbw = wave_nb(m);
+    f.nbt = tile_nb(m);
+    f.Kneg = o; o += align4((size_t)n * n);
+    f.MT = o;   o += align4((size_t)n * m);
+    f.NTn = o;  o += align4((size_t)q * n);
+    f.W = o;    o += align4((size_t)m * q);
+    f.S11i = o; o += align4((size_t)q * q);
+    f.scal = o; o += 4;
+    f.prof = o; o += 8;
+    f.Rg = o;   if (images & 1) o += (size_t)(f.nbg * (f.nbg + 1) / 2) * 256;
+    f.Rw = o;   if ((images & 2) && f.nbw > 0) o += (size_t)(f.nbw * (f.nbw + 1) / 2) * 64;
+    f.Rm = o;   if ((images & 4) && f.nbt > 0) o += tile_image_elems(f.nbt);
     f.total = o;
     return f;
 }

@@ -119,4 +119,93 @@ template <class T> QPX_DEV void batch_outer_sum_body(const Block& b, const Outer
     if (i < a.r && j < a.c) a.out[(size_t)i * a.c + j] = a.scale * sum;
 }
 
+// ------------------------------------------------------------------------------------------ small dense solve
+// x = M^-1 r for one general k x k system per workgroup (Gaussian elimination with partial pivoting, M and r in global
+// memory, both overwritten: r by x).  The one user: factor_solve_kkt_reg with equality constraints (batch.py:273-310), whose
+// -eps I in the (y, y) block is a rank-neq correction of the condensed system -- (I + eps Y) dy = dy0 with Y = d(dy)/d(ry)
+// -- a neq x neq system per QP that rounds 4 handed to torch.linalg.solve.  Off the QPFunction path and small: one pivot
+// per pair of barriers, the trailing update dealt over the 256 threads.
+template <class T> struct DenseSolveArgs {
+    int B, k;
+    T* M;             // (B, k, k), destroyed
+    T* r;             // (B, k): right-hand side in, solution out
+    int* status;      // QPX_ST_KKT_BREAKDOWN is OR-ed in when a pivot column is exactly zero / not finite (may be null)
+};
+// lds: 2 k + 257 elements + 257 ints
+QPX_LAYOUT_HD size_t dense_solve_lds_elems(int k) { return (size_t)2 * k + 257 + 260; }
+template <class T> QPX_DEV void dense_solve_body(const Block& b, const DenseSolveArgs<T>& a, int qp, T* lds)
+{
+    const int k = a.k, NT = b.nt;
+    T* M = a.M + (size_t)qp * k * k;
+    T* r = a.r + (size_t)qp * k;
+    T* prow = lds;                 // the pivot row, columns j .. k-1
+    T* mult = prow + k;            // the multipliers of column j
+    T* best = mult + k;            // NT candidates of the pivot search; [256] = the chosen |pivot|
+    int* bidx = reinterpret_cast<int*>(best + 257);         // their rows; [256] = the pivot row
+    bool ok = true;
+    for (int j = 0; j < k; ++j) {
+        // pivot search over rows j .. k-1 of column j: thread t scans rows j + t, j + t + NT, ... (first maximum wins)
+        T bv = T(-1);
+        int bi = j;
+        for (int i = j + b.tid; i < k; i += NT) {
+            const T v = abs_(M[(size_t)i * k + j]);
+            if (v > bv) { bv = v; bi = i; }
+        }
+        best[b.tid] = bv;
+        bidx[b.tid] = bi;
+        b.sync();
+        if (b.tid == 0) {
+            T mv = T(-1);
+            int mi = j;
+            const int nt = (k - j < NT) ? k - j : NT;
+            for (int t = 0; t < nt; ++t)
+                if (best[t] > mv || (best[t] == mv && bidx[t] < mi)) { mv = best[t]; mi = bidx[t]; }      // ties: the lowest row
+            best[256] = mv;
+            bidx[256] = mi;
+        }
+        b.sync();
+        const int pr = bidx[256];
+        const T pv_abs = best[256];
+        if (!(pv_abs > T(0)) || !finite_(pv_abs)) { ok = false; break; }        // uniform
+        // swap rows j and pr (columns j .. k-1 and the right-hand side), publish the pivot row
+        for (int c = j + b.tid; c < k; c += NT) {
+            const T u = M[(size_t)pr * k + c], l = M[(size_t)j * k + c];
+            M[(size_t)j * k + c] = u;
+            if (pr != j) M[(size_t)pr * k + c] = l;
+            prow[c] = u;
+        }
+        if (b.tid == 0) {
+            const T u = r[pr], l = r[j];
+            r[j] = u;
+            if (pr != j) r[pr] = l;
+        }
+        b.sync();
+        const T rp = T(1) / prow[j];
+        for (int i = j + 1 + b.tid; i < k; i += NT) mult[i] = M[(size_t)i * k + j] * rp;
+        b.sync();
+        // trailing update: element (i, c), i, c > j; and the right-hand side
+        const int w = k - j - 1;
+        for (int e = b.tid; e < w * w; e += NT) {
+            const int i = j + 1 + e / w, c = j + 1 + e % w;
+            M[(size_t)i * k + c] = fma_(-mult[i], prow[c], M[(size_t)i * k + c]);
+        }
+        const T rj = r[j];
+        for (int i = j + 1 + b.tid; i < k; i += NT) r[i] = fma_(-mult[i], rj, r[i]);
+        b.sync();
+    }
+    if (!ok) {
+        if (b.tid == 0 && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
+        for (int i = b.tid; i < k; i += NT) r[i] = Lim<T>::inf() - Lim<T>::inf();
+        return;
+    }
+    // back substitution, one unknown per barrier
+    for (int j = k - 1; j >= 0; --j) {
+        if (b.tid == 0) r[j] = r[j] / M[(size_t)j * k + j];
+        b.sync();
+        const T xj = r[j];
+        for (int i = b.tid; i < j; i += NT) r[i] = fma_(-M[(size_t)i * k + j], xj, r[i]);
+        b.sync();
+    }
+}
+
 }  // namespace qpx

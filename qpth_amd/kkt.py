@@ -230,11 +230,16 @@ a non-zero diagonal.
 
     # -- KKTSolvers.IR_UNOPT (batch.py:244-270) as a finishing stage --------------------------------
     def polish(self, p, h, b, res, steps=2, refine=0):
-        """The finishing stage: `steps` iterations of the reference's PDIPM loop (batch.py:92-198) in the original
-        variables, on residuals of the caller's data, from the loop kernel's result; the best iterate is kept.  ONE
-        kernel launch (qpx_polish, include/qpx.h v6) wherever the thread-grid / tile kernels serve the size; the
-        host-driven form below (`_polish_host`) remains for the kernel families without it (large-QP family with
-        explicit float32 `refine=k`, the workgroup kernels behind knob 1).  No host sync either way."""
+        """The finishing stage: `steps` iterations of the reference's PDIPM loop (batch.py:92-198: affine + centring-corrector)
+        in the ORIGINAL variables (x, s, z, y), on residuals of the caller's data accumulated in float64, from the loop
+        kernel's result; the best iterate is kept -- by the reference's residual ||rx|| + ||rz|| + ||ry|| + nineq mu,
+        strict <, NaN never wins (batch.py:118-139) -- so a step that does not help cannot make the answer worse.  The
+        loop kernel iterates on pre-computed products (R = G Q^-1 G^T, ...): in float32 their rounding error (cond(Q) ~
+        1e6 on the benchmark generator) is a perturbation of the PROBLEM that no number of loop iterations removes;
+        residuals against the original data do.  One C call (qpx_polish, include/qpx.h): one kernel where the thread-grid
+        / tile kernels serve the size, a stream-ordered sequence of the large-QP family's launches beyond (v7).  No host
+        sync.  (Rounds 2-4 composed this stage from torch operations on the host side for the sizes without a kernel;
+        that version now lives in tests/polish_reference.py as the step-by-step reference of the kernels.)"""
         if self.polish_ok:
             B, n, m, q = self.B, self.n, self.m, self.q
             self._check(p, n, "p")
@@ -249,85 +254,8 @@ a non-zero diagonal.
                 self.lib.polish(B, n, m, q, self.Q, p, self.G, h, self.A if q else None, b if q else None, self.blob, self.sfac,
                                 steps, refine, res.zhat, res.nu if q else None, res.lam, res.slacks, None, self.status)
             return res
-        return self._polish_host(p, h, b, res, steps, refine)
-
-    def _polish_host(self, p, h, b, res, steps=2, refine=1):
-        """`steps` iterations of the reference's PDIPM loop (batch.py:92-198: affine + centring-corrector) in the ORIGINAL
-        variables (x, s, z, y), started from the loop kernel's result, with the KKT residuals evaluated from the
-        caller's Q, G, A in float64 and every solve refined in the kernel (solve_kkt(..., refine)) where the kernel family
-        implements that (refine_ok; elsewhere the plain solve).  The loop kernel iterates on pre-computed products
-        (R = G Q^-1 G^T, ...): in float32 their rounding error (cond(Q) ~ 1e6 on the benchmark generator) is a
-        perturbation of the PROBLEM that no number of loop iterations removes; residuals against the original data do.
-        As in the reference's loop (batch.py:118-139) the BEST iterate is kept per QP -- by the reference's residual
-        ||rx|| + ||rz|| + ||ry|| + nineq mu, strict <, NaN never wins -- so a step that does not help (a QP the loop left
-        at maxIter, an oscillating mu) cannot make the answer worse.  No host sync."""
-        B, n, m, q = self.B, self.n, self.m, self.q
-        hp = torch.float64
-        if not self.refine_ok:
-            refine = 0
-        # shared parameters stay un-batched: `.to(float64)` on a stride-0 expanded view would densify it (0.5 GB at C4)
-        w = lambda X: (X[0] if (X.dim() == 3 and X.size(0) == B and X.stride(0) == 0 and B > 1) else X).to(hp)   # noqa: E731
-        Q, G = w(self.Q), w(self.G)
-        A = w(self.A) if q else None
-        mv = lambda M, x: torch.einsum("ij,bj->bi", M, x) if M.dim() == 2 else torch.einsum("bij,bj->bi", M, x)      # noqa: E731
-        mtv = lambda M, x: torch.einsum("ij,bi->bj", M, x) if M.dim() == 2 else torch.einsum("bij,bi->bj", M, x)     # noqa: E731
-        ex = lambda X: (X if X.dim() == 2 else X.unsqueeze(0).expand(B, *X.shape)).to(hp)   # noqa: E731
-        pp, hh = ex(p), ex(h)
-        bb = ex(b) if q else None
-        x, z, s = res.zhat.to(hp), res.lam.to(hp), res.slacks.to(hp)
-        y = res.nu.to(hp) if q else None
-        tiny = torch.finfo(self.dtype).tiny
-        dt = self.dtype
-
-        def step(v, dv):
-            r = torch.where(dv < 0, -v / dv.clamp_max(-tiny), torch.full_like(v, float("inf")))
-            return r.min(1, keepdim=True)[0]
-
-        def solve(d, rx, rs, rz, ry):
-            o = self.solve_kkt(d.to(dt), rx.to(dt), rs.to(dt), rz.to(dt), ry.to(dt) if q else None, refine=refine)
-            return [v.to(hp) if v is not None else None for v in o]
-
-        def residuals(x, s, z, y):
-            rx = mv(Q, x) + pp + mtv(G, z)
-            rz = mv(G, x) + s - hh
-            ry = None
-            if q:
-                rx = rx + mtv(A, y)
-                ry = mv(A, x) - bb
-            mu = (s * z).sum(1, keepdim=True).abs() / m
-            tot = rx.norm(dim=1, keepdim=True) + rz.norm(dim=1, keepdim=True) + m * mu     # batch.py:103-107
-            if q:
-                tot = tot + ry.norm(dim=1, keepdim=True)
-            return rx, rz, ry, mu, tot
-
-        rx, rz, ry, mu, best_r = residuals(x, s, z, y)
-        best_r = torch.where(torch.isfinite(best_r), best_r, torch.full_like(best_r, float("inf")))
-        bx, bs, bz, by = x, s, z, y
-        for _ in range(steps):
-            # one iteration of the reference's loop (batch.py:92-198) in float64 vector arithmetic
-            sc, zc = s.clamp_min(tiny), z.clamp_min(tiny)
-            d = zc / sc
-            dxa, dsa, dza, dya = solve(d, rx, z, rz, ry)                                        # affine direction
-            al = torch.minimum(step(z, dza), step(s, dsa)).clamp_max(1.0)
-            sig = (((s + al * dsa) * (z + al * dza)).sum(1, keepdim=True) / (s * z).sum(1, keepdim=True)) ** 3
-            rsc = (-mu * sig + dsa * dza) / sc
-            zero_n, zero_m = torch.zeros_like(rx), torch.zeros_like(rz)
-            dxc, dsc, dzc, dyc = solve(d, zero_n, rsc, zero_m, torch.zeros_like(ry) if q else None)   # corrector
-            dx, ds, dz = dxa + dxc, dsa + dsc, dza + dzc
-            alpha = (0.999 * torch.minimum(step(z, dz), step(s, ds))).clamp_max(1.0)
-            x, s, z = x + alpha * dx, s + alpha * ds, z + alpha * dz
-            if q:
-                y = y + alpha * (dya + dyc)
-            rx, rz, ry, mu, tot = residuals(x, s, z, y)
-            better = tot < best_r                                   # False for NaN: a non-finite iterate never wins
-            best_r = torch.where(better, tot, best_r)
-            bx, bs, bz = torch.where(better, x, bx), torch.where(better, s, bs), torch.where(better, z, bz)
-            if q:
-                by = torch.where(better, y, by)
-        res.zhat, res.lam, res.slacks = bx.to(self.dtype), bz.to(self.dtype), bs.to(self.dtype)
-        if q:
-            res.nu = by.to(self.dtype)
-        return res
+        raise RuntimeError("qpth_amd: no finishing stage for this size / dtype under the current knob (float32 tensors in "
+                           "float64 arithmetic do not need one; see QPFunction.__doc__)")
 
     # -- QPFunctionFn.backward (qp.py:127-182) ------------------------------------------------
     def backward(self, zhat, lam, slacks, nu, dl_dz, want=(True,) * 6, shared=(False,) * 6, refine=0):

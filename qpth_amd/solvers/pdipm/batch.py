@@ -127,7 +127,7 @@ def factor_solve_kkt_reg(Q_tilde, D, G, A, rx, rs, rz, ry, eps):
     (round 4; refused until then) is a rank-neq correction of that system: its last row reads A dx = -(ry - eps dy), and
     the solution is linear in ry, so with Y = d(dy)/d(ry) (neq solves with unit right-hand sides, independent of the
     caller's) dy solves (I + eps Y) dy = dy0 and one more solve with ry - eps dy gives the rest: neq + 2 launches of the
-    fused factor / solve kernel and one neq x neq system per QP."""
+    fused factor / solve kernel and one neq x neq system per QP (qpx_dense_solve)."""
     nineq, nz, neq, nBatch = get_sizes(G, A)
     d = _diag_of(D)
     fac = _dp.KKTFactors.build(Q_tilde, G, A)
@@ -143,7 +143,8 @@ def factor_solve_kkt_reg(Q_tilde, D, G, A, rx, rs, rz, ry, eps):
         eye = torch.eye(neq, dtype=Q_tilde.dtype, device=Q_tilde.device)
         cols = [fac.solve_kkt(dreg_b, None, None, None, eye[j].expand(nBatch, neq).contiguous())[3] for j in range(neq)]
         Y = torch.stack(cols, dim=2)                                     # Y[:, :, j] = dy for ry = e_j
-        dy_reg = torch.linalg.solve(eye + eps * Y, dy0.unsqueeze(2)).squeeze(2)
+        # (I + eps Y) dy = dy0: one general neq x neq system per QP, by the library's pivoted elimination kernel
+        dy_reg = fac.lib.dense_solve((eye + eps * Y).contiguous(), dy0.clone().contiguous(), fac.status)
         ry_eff = ry0 - eps * dy_reg
     dx, _, dz, dy = fac.solve_kkt(dreg, rx, rs_reg, rz, ry_eff)
     ds = (-rs_ - dz) / (d if d.dim() == 2 else d.unsqueeze(0))      # the second block row with the caller's d

@@ -20,6 +20,7 @@
 #include "qpx_prefac.h"
 #include "qpx_reduce.h"
 #include "qpx_big.h"
+#include "qpx_big_polish.h"
 
 // Extra bytes behind the emulated LDS block.  The sanitizer build uses 0 so that an index one element past
 // the size the launcher computed is already a reported overflow.
@@ -244,42 +245,6 @@ template <class Body> static void run_block(int nt, const Body& body)
 }
 #endif
 
-template <class T, int NS, bool kLds>
-int launch_prefactor(const PrefactorArgs<T>& a, size_t lds_bytes, void*)
-{
-    const int nt = emu_threads();
-    for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
-        T* base = reinterpret_cast<T*>(lds.data());
-        run_block(nt, [&](const Block& b) { prefactor_body<T, NS, kLds>(b, a, qp, base); });
-    }
-    return QPX_OK;
-}
-
-template <class T, int NS, bool kLds>
-int launch_ipm(const IpmArgs<T>& a, size_t lds_bytes, void*)
-{
-    const int nt = emu_threads();
-    for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
-        T* base = reinterpret_cast<T*>(lds.data());
-        run_block(nt, [&](const Block& b) { ipm_body<T, NS, kLds>(b, a, qp, base); });
-    }
-    return QPX_OK;
-}
-
-template <class T, int NS, bool kLds, bool kBw>
-int launch_kkt(const KktArgs<T>& a, size_t lds_bytes, void*)
-{
-    const int nt = emu_threads();
-    for (int qp = 0; qp < a.B; ++qp) {
-        std::vector<unsigned char> lds(lds_bytes + QPX_EMU_LDS_SLACK);
-        T* base = reinterpret_cast<T*>(lds.data());
-        run_block(nt, [&](const Block& b) { kkt_body<T, NS, kLds, kBw>(b, a, qp, base); });
-    }
-    return QPX_OK;
-}
-
 template <class T, int NBL> int launch_sweep(const PrefactorArgs<T>& a, size_t lds_bytes, void*)
 {
     for (int qp = 0; qp < a.B; ++qp) {
@@ -433,6 +398,14 @@ template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void*)
     });
     return QPX_OK;
 }
+template <class T> int launch_big_polish(const BigPolishArgs<T>& a, void*)
+{
+    const BigLayout L = big_layout(a.n, a.m, a.q);
+    big_grid(a.B, 1, 64 * kBigPolWaves, big_polish_lds_doubles(L.VP) * sizeof(double), [&](const Block& b, int qp, int, unsigned char* l) {
+        big_polish_body<T>(b, a, qp, reinterpret_cast<double*>(l));
+    });
+    return QPX_OK;
+}
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void*)
 {
     const int ns = big_pad(a.ph.m) / kWave;
@@ -455,6 +428,15 @@ template <class T> int launch_batch_outer(const OuterArgs<T>& a, int tiles, void
         }
     if (a.chunks > 1)
         for (int t = 0; t < tiles; ++t) run_block(256, [&](const Block& b) { batch_outer_sum_body<T>(b, a, t); });
+    return QPX_OK;
+}
+
+template <class T> int launch_dense_solve(const DenseSolveArgs<T>& a, void*)
+{
+    for (int qp = 0; qp < a.B; ++qp) {
+        std::vector<T> lds(dense_solve_lds_elems(a.k));
+        run_block(256, [&](const Block& b) { dense_solve_body<T>(b, a, qp, lds.data()); });
+    }
     return QPX_OK;
 }
 

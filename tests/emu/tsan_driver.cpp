@@ -71,7 +71,8 @@ int main(int argc, char** argv)
     if (qpx_polish_supported(QPX_F64, n, m, q)) {
         std::vector<double> z2 = zhat, nu2 = nu, lam2 = lam, sl2 = sl, br2(B);
         rc = qpx_polish(QPX_F64, B, n, m, q, Q.data(), (int64_t)n * n, p.data(), n, G.data(), (int64_t)m * n, h.data(), m,
-                        q ? A.data() : nullptr, (int64_t)q * n, q ? bb.data() : nullptr, q, fac.data(), (int64_t)fe, 1, 1,
+                        q ? A.data() : nullptr, (int64_t)q * n, q ? bb.data() : nullptr, q, fac.data(), (int64_t)fe, 1,
+                        qpx_refine_supported(QPX_F64, n, m, q) ? 1 : 0 /* the large-QP family's stage (v7) has no in-solve refinement */,
                         z2.data(), q ? nu2.data() : nullptr, lam2.data(), sl2.data(), br2.data(), status.data(), nullptr);
         if (rc) { fprintf(stderr, "polish rc %d\n", rc); return 2; }
         for (int s = 0; s < B; ++s)
@@ -79,8 +80,36 @@ int main(int argc, char** argv)
     }
     // the shared-parameter reduction (batch-mean of dQ as one contraction over the batch)
     std::vector<double> dQm((size_t)n * n);
-    rc = qpx_batch_outer(QPX_F64, B, n, n, dx.data(), zhat.data(), zhat.data(), dx.data(), 0.5, dQm.data(), nullptr);
+    rc = qpx_batch_outer(QPX_F64, B, n, n, dx.data(), zhat.data(), zhat.data(), dx.data(), 0.5, dQm.data(), nullptr, 0, nullptr);
     if (rc) { fprintf(stderr, "batch_outer rc %d\n", rc); return 2; }
+    {
+        // ... and its two-stage form on a batch long enough to be cut (three chunks of 256 copies of the vectors), and the
+        // small dense solve (qpx_dense_solve, v7) on a matrix that needs its pivoting
+        const int BB = 600, r = n < 20 ? n : 20;
+        std::vector<double> uu((size_t)BB * r), vv((size_t)BB * r), out2((size_t)r * r), out1((size_t)r * r);
+        for (int s = 0; s < BB; ++s)
+            for (int i = 0; i < r; ++i) { uu[(size_t)s * r + i] = dx[i] + 1e-3 * s; vv[(size_t)s * r + i] = zhat[i] - 1e-3 * s; }
+        const size_t need = qpx_batch_outer_workspace_elems(QPX_F64, BB, r, r);
+        std::vector<double> ws(need + 1);
+        if (need == 0) { fprintf(stderr, "batch_outer: no workspace asked for a batch of %d\n", BB); return 7; }
+        rc = qpx_batch_outer(QPX_F64, BB, r, r, uu.data(), vv.data(), vv.data(), uu.data(), 0.5, out2.data(), ws.data(), need, nullptr);
+        if (!rc) rc = qpx_batch_outer(QPX_F64, BB, r, r, uu.data(), vv.data(), vv.data(), uu.data(), 0.5, out1.data(), nullptr, 0, nullptr);
+        if (rc) { fprintf(stderr, "batch_outer (two stages) rc %d\n", rc); return 2; }
+        for (int i = 0; i < r * r; ++i)
+            if (std::fabs(out1[i] - out2[i]) > 1e-9 * (1.0 + std::fabs(out1[i]))) { fprintf(stderr, "batch_outer: stages disagree at %d\n", i); return 3; }
+        const int k = 9;
+        std::vector<double> Mk((size_t)k * k), rk(k), xk(k);
+        for (int i = 0; i < k; ++i) {
+            xk[i] = urand(seed) - 0.5;
+            for (int j = 0; j < k; ++j) Mk[(size_t)i * k + j] = (i == j) ? 0.0 : urand(seed) - 0.5;       // zero diagonal
+        }
+        for (int i = 0; i < k; ++i) { double acc = 0; for (int j = 0; j < k; ++j) acc += Mk[(size_t)i * k + j] * xk[j]; rk[i] = acc; }
+        int32_t st1 = 0;
+        rc = qpx_dense_solve(QPX_F64, 1, k, Mk.data(), rk.data(), &st1, nullptr);
+        if (rc || st1) { fprintf(stderr, "dense_solve rc %d status %d\n", rc, st1); return 2; }
+        for (int i = 0; i < k; ++i)
+            if (std::fabs(rk[i] - xk[i]) > 1e-8) { fprintf(stderr, "dense_solve mismatch at %d\n", i); return 3; }
+    }
     for (int i = 0; i < n * n; ++i) {
         double acc = 0;
         for (int s = 0; s < B; ++s) acc += dQ[(size_t)s * n * n + i];

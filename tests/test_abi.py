@@ -45,8 +45,10 @@ def test_hip_library_loads_and_answers_metadata(built):
     # 5.5 GB for all 65 536 QPs of C5 (<= 6 GB)
     assert 100 * 100 * 2 < lib.factor_elems(_lib.QPX_F64, 100, 100, 0) * 8 <= 250 * 1024
     assert lib.factor_elems(_lib.QPX_F64, 64, 64, 0) * 8 * 65536 <= 6 * 2 ** 30
-    assert lib.dll.qpx_fits_lds(_lib.QPX_F64, 100, 100, 0) == 1      # C2 runs LDS-resident in f64
-    assert lib.dll.qpx_fits_lds(_lib.QPX_F64, 500, 500, 0) == 0      # C4 does not
+    assert lib.dll.qpx_can_share_factors(_lib.QPX_F64, 100, 100, 0) == 1      # C2: tile kernels, the blob is read-only
+    assert lib.dll.qpx_can_share_factors(_lib.QPX_F64, 500, 500, 0) == 0      # C4: per-QP work matrices live in it
+    assert lib.dll.qpx_kernel_family(_lib.QPX_F64, 100, 100, 0) == _lib.FAMILY_TILE
+    assert lib.dll.qpx_kernel_family(_lib.QPX_F64, 500, 500, 0) == _lib.FAMILY_BIG
     assert b"not supported" in lib.dll.qpx_strerror(-2)
 
 

@@ -113,15 +113,6 @@ def test_broadcast_parameters_and_mean_reduced_grads(name):
         assert np.abs(gr - g[k]).max() <= TOL * max(1.0, np.abs(g[k]).max()), k
 
 
-def test_matrices_in_hbm_path(monkeypatch):
-    """sizes that do not fit 160 KiB of LDS work in place in the factor blob (forced here)."""
-    monkeypatch.setenv("QPX_EMU_LDS_BYTES", "1500")
-    g = load_golden("c3s_b4_n20_m10_q4_f64")
-    z, grads = run_qpf([g[k] for k in ("Q", "p", "G", "h", "A", "b")], g["dl_dz"], threads=64)
-    assert rel_err(z, g["zhat"]).max() < TOL
-    assert np.abs(grads[0] - g["dQ"]).max() <= 10 * TOL * max(1.0, np.abs(g["dQ"]).max())
-
-
 def test_two_slots_and_four_waves():
     """nz > 64 (two register slots per lane) with a 256-thread workgroup, vs the oracle."""
     Q, p, G, h, A, b = problems.prof_qp(1, 70, 66, 3, seed=5)
@@ -362,9 +353,9 @@ def test_batch_of_one_uses_the_reference_stall_counter():
 
 
 # every form of the loop kernel the dispatcher can pick (include/qpx.h, qpx_set_ipm_variant):
-# 1 = workgroup kernels, 2 = wave kernel, +256 / +512 = 16x16 / 8x8 thread grid, +1024 = matrix-core
+# 3 = the large-QP family forced at a small size, +256 / +512 = 16x16 / 8x8 thread grid, +1024 = matrix-core
 # tiles with 1 / 2 / 4 waves per QP (+2048 / +4096 / +8192)
-LOOP_FORMS = [1, 256, 512, 1024 + 2048, 1024 + 4096, 1024 + 8192]
+LOOP_FORMS = [3, 256, 512, 1024 + 2048, 1024 + 4096, 1024 + 8192]
 
 
 @pytest.mark.parametrize("variant", LOOP_FORMS)
@@ -758,6 +749,38 @@ def test_batch_contraction_in_two_stages(shape, dtype):
         assert (o.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("k", [1, 3, 40, 130])
+def test_small_dense_solve(k, dtype):
+    """qpx_dense_solve (v7): one general k x k system per workgroup by pivoted elimination -- the neq x neq correction of
+    factor_solve_kkt_reg (batch.py:273-310) -- against numpy, on matrices that NEED the pivoting (zero diagonal), and a
+    singular one (status bit, NaNs)."""
+    from emu.harness import emu_lib
+    from qpth_amd import _lib
+    rng = np.random.RandomState(k)
+    B = 3
+    M = rng.randn(B, k, k)
+    if k > 1:
+        M[:, np.arange(k), np.arange(k)] = 0.0                       # every natural pivot is zero
+    M[0] += 3.0 * np.eye(k)[::-1] if k > 1 else 0.0
+    r = rng.randn(B, k)
+    if k > 1:
+        M[2, :, 0] = M[2, :, 1]                                      # QP 2: two equal columns = singular
+    ref = [np.linalg.solve(M[i], r[i]) for i in range(2 if k > 1 else B)]
+    tM, tr = torch.tensor(M, dtype=dtype), torch.tensor(r, dtype=dtype)
+    st = torch.zeros(B, dtype=torch.int32)
+    with emulated(256):
+        x = emu_lib().dense_solve(tM.clone(), tr.clone(), st).numpy()
+    tol = 1e-9 if dtype == torch.float64 else 5e-3
+    for i, xr in enumerate(ref):
+        assert np.abs(x[i] - xr).max() <= tol * max(1.0, np.abs(xr).max()), (i, np.abs(x[i] - xr).max())
+        assert st[i] == 0
+    if k > 1:
+        # (in floating point the elimination of a singular matrix may end on a tiny pivot instead of an exact zero: either
+        # the status bit, or a solution that does not satisfy the system)
+        assert (st[2] & _lib.ST_KKT_BREAKDOWN) or not np.allclose(M[2] @ x[2], r[2], atol=1e-6)
+
+
 def test_iterative_refinement_of_the_kkt_solve():
     """solve_kkt_ir (batch.py:244-270): refinement on the residual of the ORIGINAL system inside the kernel (residuals
     accumulated in float64).  In float32 on the benchmark generator one step cuts the KKT residual by > 50x; in
@@ -931,13 +954,16 @@ def test_float32_finishing_steps_reach_the_reference_accuracy():
 
 @pytest.mark.parametrize("shape,dtype,variant", [((3, 30, 20, 4), torch.float32, 0), ((2, 100, 100, 0), torch.float32, 0),
                                                  ((3, 30, 20, 4), torch.float64, 0), ((2, 20, 40, 3), torch.float64, 256),
-                                                 ((2, 100, 100, 0), torch.float64, 0), ((2, 30, 50, 5), torch.float64, 0)])
+                                                 ((2, 100, 100, 0), torch.float64, 0), ((2, 30, 50, 5), torch.float64, 0),
+                                                 # knob 3: the large-QP family's finishing stage (qpx_big_polish.h, round 5), two and three blocks of 64
+                                                 ((2, 70, 66, 3), torch.float32, 3), ((2, 130, 100, 0), torch.float64, 3), ((2, 66, 130, 5), torch.float64, 3)])
 def test_finishing_stage_kernel_equals_the_host_version(shape, dtype, variant):
     """qpx_polish (include/qpx.h v6): the finishing stage as ONE kernel -- thread-grid form (float32; float64 with
     knob 256) and matrix-core tile forms (float64: one wave per QP at 2 tile rows, the chain-wave form at 4 and 7) --
-    against the host-driven version it replaces (KKTFactors._polish_host: the same iteration as float64 tensor ops), from
+    against the host-composed version it replaced (tests/polish_reference.py: the same iteration as float64 tensor ops), from
     the same start iterate, step by step: equal to rounding, equality constraints included.  The start iterate is the
     loop kernel's result after THREE iterations, so that the steps have something to do."""
+    from polish_reference import polish_reference
     from qpth_amd.kkt import KKTFactors
     B, n, m, q = shape
     f32 = dtype == torch.float32
@@ -948,7 +974,7 @@ def test_finishing_stage_kernel_equals_the_host_version(shape, dtype, variant):
         assert fac.lib.dll.qpx_polish_supported(0 if f32 else 1, n, m, q) == 1
         for steps in (1, 2):
             outs = []
-            for fn in (fac.polish, fac._polish_host):
+            for fn in (fac.polish, lambda *a_, **k_: polish_reference(fac, *a_, **k_)):
                 res = fac.ipm(tp, th, tb, maxIter=3)
                 res = fn(tp, th, tb, res, steps=steps, refine=1)
                 outs.append([res.zhat.numpy().copy(), res.lam.numpy().copy(), res.slacks.numpy().copy()] + ([res.nu.numpy().copy()] if q else []))
@@ -1006,9 +1032,7 @@ def test_f32_wide_abi_surface():
         assert dll.qpx_supported(_lib.QPX_F32_WIDE, 500, 500, 0) == 0           # the large-QP family widens on load too (round 4)
         assert dll.qpx_supported(_lib.QPX_F64, 500, 500, 0) == 0
         assert dll.qpx_factor_elems(_lib.QPX_F32_WIDE, 100, 100, 0) == dll.qpx_factor_elems(_lib.QPX_F64, 100, 100, 0)
-        old = dll.qpx_set_ipm_variant(1)                                          # workgroup kernels forced: not served
-        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 100, 100, 0) == -2
-        dll.qpx_set_ipm_variant(old)
+        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 600, 100, 0) == -2           # beyond 512 per dimension: nobody serves it
         # refinement reads Q, G, A in the kernels' own type: refused, loudly
         g = load_golden("c3s_b4_n20_m10_q4_f64")
         tq = tens([np.asarray(g[k], np.float32) for k in ("Q", "p", "G", "h", "A", "b")], torch.float32, grad=False)

@@ -816,9 +816,9 @@ def test_large_qp_hbm_resident_path(dev):
 
 
 # ---------------------------------------------------------------- 4. every form of the loop kernel
-# include/qpx.h, qpx_set_ipm_variant: 1 = workgroup kernels, 3 = the large-QP multi-kernel family (neq = 0), +256 / +512 = 16x16 / 8x8
+# include/qpx.h, qpx_set_ipm_variant: 3 = the large-QP multi-kernel family forced at small sizes, +256 / +512 = 16x16 / 8x8
 # thread grid, +1024 = matrix-core tiles with 1 / 2 / 4 waves per QP (+2048 / +4096 / +8192)
-LOOP_FORMS = [1, 3, 256, 512, 1024 + 2048, 1024 + 4096, 1024 + 8192]
+LOOP_FORMS = [3, 256, 512, 1024 + 2048, 1024 + 4096, 1024 + 8192]
 
 
 @pytest.mark.parametrize("variant", LOOP_FORMS)
