@@ -38,6 +38,7 @@ QPX_LAYOUT_HD size_t big_blk(int ld, int rb, int cb) { return ((size_t)rb * (ld 
 QPX_LAYOUT_HD size_t big_at(int ld, int i, int j) { return big_blk(ld, i >> 6, j >> 6) + (size_t)(i & 63) * kBB + (j & 63); }
 constexpr int kBigPolVecs = 32;      // element-sized vectors of the finishing stage's region (BigLayout::pol)
 constexpr int kMaxSide = 3;          // side streams the host may spread the parts of a batch over (qpx_api.inc: big_split)
+constexpr int kPoolSlots = 2 * kMaxSide + 1;      // ... + one helper stream per part (R z' beside the factorisation)
 constexpr int kBL = kBB + 2;     // LDS row stride of a staged block (elements): 2-way bank conflicts at most
 QPX_LAYOUT_HD int big_pad(int x) { return (x + kBB - 1) / kBB * kBB; }
 
@@ -748,6 +749,83 @@ template <class T> QPX_DEV void big_gemv_body(const Block& b, const BigGemvArgs<
             for (int ww = 0; ww < nw; ++ww) s += part[ww * kWave + lane];
             y[j] = fma_(a.alpha, s, y0 ? a.beta * y0[j] : T(0));
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ symmetric mat-vec
+// y = R x for the symmetric R of the loop (R z' once per pass, R 1 once per forward) from its LOWER block triangle alone
+// (round 5): the row-dot kernel above read all of R -- 2 MB per QP and pass at C4, 258 MB per launch, an eighth of the bytes
+// a pass moves -- and was the only reader of the upper triangle, which the pre-factorisation therefore no longer writes
+// (115 MB of mirrored tiles).  Workgroup (qp, I) owns block row I: every block (I, J), J <= I, is loaded once, row by
+// row (wave w: rows 16 w .. 16 w + 15, one 512-byte segment per load) and used twice -- times x_J for the rows' dots
+// (per-lane partial products accumulated over J, one lane reduction per row at the end) and, for J < I, times x_I for
+// the block's contribution to y_J (per-lane column sums, the four waves' sums met in LDS), which goes to a per-(I, J) slot
+// of the workspace.  A second, tiny launch adds, in a fixed order, y_J = rows_J + sum_{I > J} slot(I, J).
+template <class T> struct BigSymvArgs {
+    int B, rows;                          // logical order of R (the padded blocks are identity / zero: loads stay unconditional)
+    int stage;                            // 0: block rows -> ws; 1: the sum -> y
+    const T* M; size_t sM; int ld;
+    const T* x; size_t sx;
+    T* y; size_t sy;
+    T* ws; size_t sws;                    // per QP: (nb + nb * nb) * 64 elements -- rows part, then slot (I, J) at (nb + I nb + J) * 64
+    const int* ctrl; size_t sctrl; int check_stop;
+};
+QPX_LAYOUT_HD size_t big_symv_ws_elems(int np) { const size_t nb = np / kBB; return (nb + nb * nb) * kBB; }
+// LDS: x_I and the current x_J (2 x 64) + 4 x 64 column partial sums
+QPX_LAYOUT_HD size_t big_symv_lds_elems() { return (size_t)6 * kBB; }
+template <class T> QPX_DEV void big_symv_body(const Block& b, const BigSymvArgs<T>& a, int qp, int I, T* lds)
+{
+    if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
+    const int nb = a.ld / kBB;
+    T* ws = a.ws + (size_t)qp * a.sws;
+    const int lane = b.lane(), w = b.uniform(b.wave());
+    if (a.stage == 1) {
+        T* y = a.y + (size_t)qp * a.sy;
+        for (int i = b.tid; i < a.rows; i += b.nt) {
+            const int J = i >> 6, c = i & 63;
+            T sum = ws[(size_t)J * kBB + c];
+            for (int I2 = J + 1; I2 < nb; ++I2) sum += ws[((size_t)nb + (size_t)I2 * nb + J) * kBB + c];
+            y[i] = sum;
+        }
+        return;
+    }
+    const T* M = a.M + (size_t)qp * a.sM;
+    const T* x = a.x + (size_t)qp * a.sx;
+    T* xI = lds;                 // x of this block row (the coefficients of the column sums)
+    T* xJ = xI + kBB;            // x of the current block column
+    T* part = xJ + kBB;          // 4 x 64
+    constexpr int RW = 16;       // rows of a block a wave owns
+    if (b.tid < kBB) { const int i = I * kBB + b.tid; xI[b.tid] = i < a.rows ? x[i] : T(0); }
+    T racc[RW];
+#pragma unroll
+    for (int u = 0; u < RW; ++u) racc[u] = T(0);
+    for (int J = 0; J <= I; ++J) {
+        b.sync();                // xJ / part of the previous block are consumed
+        if (b.tid < kBB) { const int i = J * kBB + b.tid; xJ[b.tid] = i < a.rows ? x[i] : T(0); }
+        const T* blk = M + big_blk(a.ld, I, J) + (size_t)(RW * w) * kBB + lane;
+        T v[RW];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) v[u] = blk[(size_t)u * kBB];
+        b.sync();
+        const T xv = xJ[lane];
+        T cacc = T(0);
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            racc[u] = fma_(v[u], xv, racc[u]);
+            cacc = fma_(v[u], xI[RW * w + u], cacc);
+        }
+        if (J < I) {
+            part[w * kBB + lane] = cacc;
+            b.sync();
+            if (b.tid < kBB)
+                ws[((size_t)nb + (size_t)I * nb + J) * kBB + b.tid] = (part[b.tid] + part[kBB + b.tid]) + (part[2 * kBB + b.tid] + part[3 * kBB + b.tid]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RW; ++u) racc[u] = wave_sum(b, racc[u]);
+    if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < RW; ++u) ws[(size_t)I * kBB + RW * w + u] = racc[u];
     }
 }
 

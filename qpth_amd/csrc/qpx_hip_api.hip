@@ -12,8 +12,10 @@ namespace qpx {
 // One pool of side streams + events per (host thread, device), created on first use and kept for the life of the
 // thread.  Fork / join are event record + stream wait: stream-ordered, legal under stream capture, no host sync.
 struct SidePool {
-    hipStream_t s[kMaxSide + 1];          // [0, kMaxSide): the parts of a batch; [kMaxSide]: the helper stream of the loop (R z' beside the factorisation)
-    hipEvent_t fork, done[kMaxSide + 1];
+    // [0, kMaxSide): the streams of the parts of a batch beyond the first (which runs on the caller's);
+    // [kMaxSide, kPoolSlots): one helper stream per part (R z' beside the factorisation), part i -> kMaxSide + i
+    hipStream_t s[kPoolSlots];
+    hipEvent_t fork[kPoolSlots], done[kPoolSlots];
     bool ok = false;
 };
 constexpr int kMaxDev = 16;
@@ -29,19 +31,20 @@ __global__ void k_stream_delay(long long ticks)
 int stream_fork(void* caller, int nside, void** side, int delay_us, int first)
 {
     int dev = 0;
-    if (nside < 1 || first < 0 || first + nside > kMaxSide + 1 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
+    if (nside < 1 || first < 0 || first + nside > kPoolSlots || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
     SidePool& p = g_side[dev];
     if (!p.ok) {
-        if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return QPX_ERR_LAUNCH;
-        for (int i = 0; i < kMaxSide + 1; ++i)
+        for (int i = 0; i < kPoolSlots; ++i)
             if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&p.fork[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) != hipSuccess)
                 return QPX_ERR_LAUNCH;
         p.ok = true;
     }
-    if (hipEventRecord(p.fork, (hipStream_t)caller) != hipSuccess) return QPX_ERR_LAUNCH;
+    // (one fork event per first slot: two parts of a batch fork their helper streams from different streams at once)
+    if (hipEventRecord(p.fork[first], (hipStream_t)caller) != hipSuccess) return QPX_ERR_LAUNCH;
     for (int i = 0; i < nside; ++i) {
-        if (hipStreamWaitEvent(p.s[first + i], p.fork, 0) != hipSuccess) return QPX_ERR_LAUNCH;
+        if (hipStreamWaitEvent(p.s[first + i], p.fork[first], 0) != hipSuccess) return QPX_ERR_LAUNCH;
         if (delay_us > 0) {
             long long us = (long long)delay_us * (i + 1);
             if (us > 10000) us = 10000;
@@ -55,7 +58,7 @@ int stream_fork(void* caller, int nside, void** side, int delay_us, int first)
 int stream_join(void* caller, int nside, void* const* side, int first)
 {
     int dev = 0;
-    if (nside < 1 || first < 0 || first + nside > kMaxSide + 1 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
+    if (nside < 1 || first < 0 || first + nside > kPoolSlots || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
     SidePool& p = g_side[dev];
     for (int i = 0; i < nside; ++i) {
         if (hipEventRecord(p.done[first + i], (hipStream_t)side[i]) != hipSuccess) return QPX_ERR_LAUNCH;

@@ -296,6 +296,7 @@ template <class T> __global__ __launch_bounds__(64 * kTrsvNW) void k_big_trsv(Bi
     big_trsv_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
 }
 QPX_BIG_KERNEL(k_big_gemv, BigGemvArgs, (big_gemv_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
+QPX_BIG_KERNEL(k_big_symv, BigSymvArgs, (big_symv_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
 QPX_BIG_KERNEL(k_big_vec, BigVecArgs, (big_vec_body<T>(b, a, (int)blockIdx.x)), 256)
 QPX_BIG_KERNEL(k_big_kkt, BigKktArgs, (big_kkt_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y)), 256)
 template <class T, int NS> __global__ __launch_bounds__(64) void k_big_phase(BigPhaseArgs<T> a)
@@ -353,6 +354,11 @@ template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* s)
     const int outs = a.trans ? a.cols : a.rows;
     return big_launch(k_big_gemv<T>, a, a.B, (outs + kBB - 1) / kBB, 256, big_gemv_lds_elems() * sizeof(T), s, f);
 }
+template <class T> int launch_big_symv(const BigSymvArgs<T>& a, void* s)
+{
+    static BigLdsFlags f;
+    return big_launch(k_big_symv<T>, a, a.B, a.stage == 0 ? a.ld / kBB : 1, 256, big_symv_lds_elems() * sizeof(T), s, f);
+}
 template <class T> int launch_big_vec(const BigVecArgs<T>& a, void* s) { static BigLdsFlags f; return big_launch(k_big_vec<T>, a, a.B, 1, 256, 0, s, f); }
 template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* s) { static BigLdsFlags f; return big_launch(k_big_kkt<T>, a, a.B, gy, 256, 0, s, f); }
 template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* s)
@@ -402,7 +408,7 @@ QPX_INSTB(launch_big_solve, BigSolveArgs) QPX_INSTB(launch_big_diag, BigDiagArgs
 template int launch_big_pack<QPX_TU_REAL>(const BigPackArgs<QPX_TU_REAL>&, int, void*);
 template int launch_big_kkt<QPX_TU_REAL>(const BigKktArgs<QPX_TU_REAL>&, int, void*);
 QPX_INSTB(launch_big_panel, BigPanelArgs) QPX_INSTB(launch_big_gemm, BigGemmArgs) QPX_INSTB(launch_big_trsv, BigTrsvArgs) QPX_INSTB(launch_big_gemv, BigGemvArgs)
-QPX_INSTB(launch_big_vec, BigVecArgs) QPX_INSTB(launch_big_phase, BigPhaseArgs)
+QPX_INSTB(launch_big_vec, BigVecArgs) QPX_INSTB(launch_big_phase, BigPhaseArgs) QPX_INSTB(launch_big_symv, BigSymvArgs)
 #endif
 
 #if QPX_TU_KERNEL == 10

@@ -43,6 +43,7 @@ template <class T> int launch_big_panel(const BigPanelArgs<T>& a, void* stream);
 template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* stream);
 template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* stream);
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* stream);
+template <class T> int launch_big_symv(const BigSymvArgs<T>& a, void* stream);
 template <class T> int launch_big_vec(const BigVecArgs<T>& a, void* stream);
 template <class T> int launch_big_kkt(const BigKktArgs<T>& a, int gy, void* stream);
 template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* stream);
@@ -54,7 +55,7 @@ template <class T> int launch_big_polish(const BigPolishArgs<T>& a, void* stream
 // enqueued on `caller` so far; stream_join: `caller` waits (events) for everything enqueued on them.  Neither
 // synchronises the host.  delay_us > 0: side stream i first sleeps i * delay_us (one idle wave), which sets the
 // parts out of phase with each other.
-// `first`: pool slot of side[0] -- [0, kMaxSide) are the parts' streams, kMaxSide the helper stream of the loop.
+// `first`: pool slot of side[0] -- [0, kMaxSide) are the parts' streams, kMaxSide + i the helper stream of part i's loop.
 int stream_fork(void* caller, int nside, void** side, int delay_us, int first = 0);
 int stream_join(void* caller, int nside, void* const* side, int first = 0);
 

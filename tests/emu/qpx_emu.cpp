@@ -364,6 +364,11 @@ template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void*)
     big_grid(a.B, (outs + kBB - 1) / kBB, 256, big_gemv_lds_elems() * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemv_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
     return QPX_OK;
 }
+template <class T> int launch_big_symv(const BigSymvArgs<T>& a, void*)
+{
+    big_grid(a.B, a.stage == 0 ? a.ld / kBB : 1, 256, big_symv_lds_elems() * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_symv_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
+    return QPX_OK;
+}
 template <class T> int launch_big_vec(const BigVecArgs<T>& a, void*)
 {
     big_grid(a.B, 1, 256, 0, [&](const Block& b, int qp, int, unsigned char*) { big_vec_body<T>(b, a, qp); });
