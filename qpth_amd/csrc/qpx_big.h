@@ -36,6 +36,7 @@ constexpr int kBB = 64;          // block order
 constexpr int kBE = kBB * kBB;   // elements of a block
 QPX_LAYOUT_HD size_t big_blk(int ld, int rb, int cb) { return ((size_t)rb * (ld / kBB) + cb) * kBE; }
 QPX_LAYOUT_HD size_t big_at(int ld, int i, int j) { return big_blk(ld, i >> 6, j >> 6) + (size_t)(i & 63) * kBB + (j & 63); }
+constexpr int kDiagNoWt = 4;         // `tile` bit of the diagonal-block eliminations: do not store W_kk^T
 constexpr int kBigPolVecs = 32;      // element-sized vectors of the finishing stage's region (BigLayout::pol)
 constexpr int kMaxSide = 3;          // side streams the host may spread the parts of a batch over (qpx_api.inc: big_split)
 constexpr int kPoolSlots = 2 * kMaxSide + 1;      // ... + one helper stream per part (R z' beside the factorisation)
@@ -138,7 +139,7 @@ QPX_LAYOUT_HD size_t big_panel_lds_elems() { return (size_t)kBB * kBL + big_diag
 // D(i, j) = element (i, j) of the 64 x 64 block (any source: global memory, or the LDS tile a trailing update has just
 // finished); W: the 2 x 64 x 64 output of the block; lds: 3 * 64 + 8 elements of scratch.  All 256 threads.
 template <class T, class Elem>
-QPX_DEV void big_diag_block_grid(const Block& b, Elem&& D, T* W, int* ctrl, int fail_bit, T* lds)
+QPX_DEV void big_diag_block_grid(const Block& b, Elem&& D, T* W, int* ctrl, int fail_bit, T* lds, bool wt = true)
 {
     constexpr int GS = 16, NBL = kBB / GS;
     const GridPos<GS> g(b);
@@ -168,7 +169,7 @@ QPX_DEV void big_diag_block_grid(const Block& b, Elem&& D, T* W, int* ctrl, int 
                 v = (j < i) ? E[gidx(li, lj)] * rs : (j == i ? rs : T(0));
             }
             W[i * kBB + j] = v;
-            Wt[j * kBB + i] = v;
+            if (wt) Wt[j * kBB + i] = v;
         }
 }
 
@@ -179,7 +180,7 @@ QPX_DEV void big_diag_block_grid(const Block& b, Elem&& D, T* W, int* ctrl, int 
 // is done with D before it writes, the other waves only touch tiles above the diagonal, which D is never asked
 // for); scr: big_diag_scratch_elems().  All 256 threads.
 template <class Elem>
-QPX_DEV void big_diag_block_tile(const Block& b, Elem&& D, double* W, int* ctrl, int fail_bit, double* stage, double* scr)
+QPX_DEV void big_diag_block_tile(const Block& b, Elem&& D, double* W, int* ctrl, int fail_bit, double* stage, double* scr, bool wt = true)
 {
     using TM = TileMat<kBB / 16, 1>;
     double* rd = scr + TM::scratch_elems();
@@ -229,7 +230,7 @@ QPX_DEV void big_diag_block_tile(const Block& b, Elem&& D, double* W, int* ctrl,
     for (int e = b.tid; e < kBB * kBB; e += b.nt) {
         const int i = e >> 6, j = e & 63;
         W[e] = stage[i * kBL + j];
-        Wt[e] = stage[j * kBL + i];
+        if (wt) Wt[e] = stage[j * kBL + i];
     }
 }
 
@@ -239,7 +240,7 @@ QPX_DEV void big_diag_block_tile(const Block& b, Elem&& D, double* W, int* ctrl,
 // every lower tile is read and later written by the one wave that owns it, the chain wave zeroes the tiles above
 // the diagonal, which D is never asked for.
 template <class Elem>
-QPX_DEV void big_diag_block_chain(const Block& b, Elem&& D, double* W, int* ctrl, int fail_bit, double* stage, double* scr)
+QPX_DEV void big_diag_block_chain(const Block& b, Elem&& D, double* W, int* ctrl, int fail_bit, double* stage, double* scr, bool wt = true)
 {
     using TM = TileMat<kBB / 16, 4, true>;
     double* rd = scr + TM::scratch_elems();
@@ -298,7 +299,7 @@ QPX_DEV void big_diag_block_chain(const Block& b, Elem&& D, double* W, int* ctrl
     for (int e = b.tid; e < kBB * kBB; e += b.nt) {
         const int i = e >> 6, j = e & 63;
         W[e] = stage[i * kBL + j];
-        Wt[e] = stage[j * kBL + i];
+        if (wt) Wt[e] = stage[j * kBL + i];
     }
 }
 
@@ -307,17 +308,21 @@ QPX_DEV void big_diag_block_chain(const Block& b, Elem&& D, double* W, int* ctrl
 template <class T, class Elem>
 QPX_DEV void big_diag_block(const Block& b, Elem&& D, T* W, int* ctrl, int fail_bit, T* stage, T* scr, int tile)
 {
+    // tile bit 2 (kDiagNoWt): W_kk alone -- nothing reads the transposed copy of this factor's blocks (round 5: the
+    // substitutions take both directions from the rows of W_kk; only the factor of S11 still wants W_kk^T)
+    const bool wt = !(tile & kDiagNoWt);
+    tile &= 3;
     if constexpr (std::is_same<T, double>::value) {
         if (tile == 2) {
-            big_diag_block_chain(b, D, W, ctrl, fail_bit, stage, scr);
+            big_diag_block_chain(b, D, W, ctrl, fail_bit, stage, scr, wt);
             return;
         }
         if (tile) {
-            big_diag_block_tile(b, D, W, ctrl, fail_bit, stage, scr);
+            big_diag_block_tile(b, D, W, ctrl, fail_bit, stage, scr, wt);
             return;
         }
     }
-    big_diag_block_grid<T>(b, D, W, ctrl, fail_bit, scr);
+    big_diag_block_grid<T>(b, D, W, ctrl, fail_bit, scr, wt);
 }
 
 template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArgs<T>& a, int qp, T* lds)
@@ -328,7 +333,7 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
     const int k0 = a.k * kBB;
     const T* dg = a.dg ? a.dg + (size_t)qp * a.sdg + k0 : nullptr;
     T* W = a.W + (size_t)qp * a.sW + (size_t)a.k * 2 * kBB * kBB;
-    if (std::is_same<T, double>::value && a.tile) {
+    if (std::is_same<T, double>::value && (a.tile & 3)) {
         // the matrix-core form reads the block with one wave: bring it into LDS with all four first (coalesced rows)
         for (int e = b.tid; e < kBB * kBB; e += b.nt) {
             const int i = e >> 6, j = e & 63;
@@ -344,7 +349,7 @@ template <class T> QPX_DEV void big_panel_body(const Block& b, const BigPanelArg
         T v = M[i * kBB + j];
         if (dg && i == j) v += dg[i];
         return v;
-    }, W, ctrl, a.fail_bit, lds, lds + kBB * kBL, 0);
+    }, W, ctrl, a.fail_bit, lds, lds + kBB * kBL, a.tile & kDiagNoWt);
 }
 
 // ------------------------------------------------------------------------------------------ GEMM tile
