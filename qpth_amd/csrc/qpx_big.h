@@ -524,7 +524,7 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
 // The matrix entries of a block step do not depend on the solution: the first two off-diagonal blocks of step k + 1 and
 // its rows of W (twelve loads per lane) are issued BEFORE step k's arithmetic and fly under its chain of reductions and
 // barriers -- the round-4 kernel started every step with a cold round trip to HBM (~2 of its ~5 us per step); the rest
-// of a step streams eight loads per lane at a time.  (All of a step one step ahead -- 2 x 32 doubles per lane -- does not
+// of a step is issued at once when the step starts.  (All of a step one step ahead -- 2 x 32 doubles per lane -- does not
 // fit the 128 registers of a sixteen-wave workgroup.)  The barriers of this kernel therefore wait for LDS traffic only
 // (Block::sync_lds): the waves exchange nothing through global memory.
 template <class T> struct BigTrsvArgs {
@@ -543,7 +543,7 @@ QPX_LAYOUT_HD size_t big_trsv_lds_elems(int np) { return (size_t)np + (size_t)(k
 template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<T>& a, int qp, T* lds)
 {
     if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
-    constexpr int NW = kTrsvNW, RW = kTrsvRows, PF = kTrsvPrefetch;
+    constexpr int NW = kTrsvNW, RW = kTrsvRows, PF = kTrsvPrefetch, MS = 512 / kBB - 1 - kTrsvPrefetch;      // (MS: streamed blocks of a step at the largest size)
     const int np = a.nb * kBB;
     T* xs = lds;                 // the vector
     T* part = xs + np;           // NW x 64 partial sums (backward direction)
@@ -614,14 +614,16 @@ template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<
                 for (int u = 0; u < RW; ++u) acc[u] = fma_(mv[u], xj[NW * u], acc[u]);
             }
         };
-        // the blocks beyond the prefetched ones stream through two blocks (eight loads per lane) at a time
-        for (int jb = PF; jb < nblk; jb += 2) {
-            T m0[RW], m1[RW];
-            const bool two = jb + 1 < nblk;
-            ld_rows(rows_of(k, jb), m0);
-            ld_rows(rows_of(k, two ? jb + 1 : jb), m1);
-            mac(jb, m0);
-            if (two) mac(jb + 1, m1);
+        // the blocks beyond the prefetched ones: ALL their loads at once (at most five blocks = twenty loads per lane at the
+        // largest size) -- in pairs, the largest steps were three dependent round trips to HBM long
+        {
+            T ms[MS][RW];
+#pragma unroll
+            for (int j = 0; j < MS; ++j)
+                if (PF + j < nblk) ld_rows(rows_of(k, PF + j), ms[j]);
+#pragma unroll
+            for (int j = 0; j < MS; ++j)
+                if (PF + j < nblk) mac(PF + j, ms[j]);
         }
 #pragma unroll
         for (int jb = 0; jb < PF; ++jb)
@@ -1258,13 +1260,17 @@ template <class T> struct BigSolveArgs {
     int negate, post_phase;      // post_phase < 0: none
     int pre_phase;               // > 0: the wave-0 phase that writes the right-hand side (and the stop flag) first
 };
+template <class T, int NS> QPX_DEV_CALL void big_phase_call(const Block& b, const BigPhaseArgs<T>& ph, int qp)
+{
+    big_phase_body<T, NS>(b, ph, qp);
+}
 template <class T, int NS> QPX_DEV void big_solve_body(const Block& b, const BigSolveArgs<T>& a, int qp, T* lds)
 {
     if (a.pre_phase > 0) {
         if (b.uniform(b.wave()) == 0) {
             BigPhaseArgs<T> ph = a.ph;
             ph.phase = a.pre_phase;
-            big_phase_body<T, NS>(b, ph, qp);
+            big_phase_call<T, NS>(b, ph, qp);
         }
         b.sync();                                    // right-hand side and stop flag are in global memory for every wave
     }
@@ -1279,7 +1285,7 @@ template <class T, int NS> QPX_DEV void big_solve_body(const Block& b, const Big
         if (b.uniform(b.wave()) == 0) {
             BigPhaseArgs<T> ph = a.ph;
             ph.phase = a.post_phase;
-            big_phase_body<T, NS>(b, ph, qp);
+            big_phase_call<T, NS>(b, ph, qp);
         }
     }
 }
