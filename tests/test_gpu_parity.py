@@ -975,6 +975,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields(dev):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
     assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1
+    # the default command also carries BASELINE.json's C3 and C4, timed the same way behind the headline (round 5)
+    side = d["extra"]["other_baseline_configs"]
+    for key, B in (("c3", 512), ("c4", 128)):
+        assert side[key]["value"] > 0 and abs(side[key]["value"] - B / (side[key]["ms_per_step"] * 1e-3)) < 1e-6 * side[key]["value"]
 
 
 def test_max_iter_and_eps_are_honoured(dev):
