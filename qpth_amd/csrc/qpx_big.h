@@ -1260,17 +1260,13 @@ template <class T> struct BigSolveArgs {
     int negate, post_phase;      // post_phase < 0: none
     int pre_phase;               // > 0: the wave-0 phase that writes the right-hand side (and the stop flag) first
 };
-template <class T, int NS> QPX_DEV_CALL void big_phase_call(const Block& b, const BigPhaseArgs<T>& ph, int qp)
-{
-    big_phase_body<T, NS>(b, ph, qp);
-}
 template <class T, int NS> QPX_DEV void big_solve_body(const Block& b, const BigSolveArgs<T>& a, int qp, T* lds)
 {
     if (a.pre_phase > 0) {
         if (b.uniform(b.wave()) == 0) {
             BigPhaseArgs<T> ph = a.ph;
             ph.phase = a.pre_phase;
-            big_phase_call<T, NS>(b, ph, qp);
+            big_phase_body<T, NS>(b, ph, qp);
         }
         b.sync();                                    // right-hand side and stop flag are in global memory for every wave
     }
@@ -1285,7 +1281,7 @@ template <class T, int NS> QPX_DEV void big_solve_body(const Block& b, const Big
         if (b.uniform(b.wave()) == 0) {
             BigPhaseArgs<T> ph = a.ph;
             ph.phase = a.post_phase;
-            big_phase_call<T, NS>(b, ph, qp);
+            big_phase_body<T, NS>(b, ph, qp);
         }
     }
 }

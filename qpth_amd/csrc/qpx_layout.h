@@ -93,11 +93,18 @@ QPX_LAYOUT_HD int sweep_nb(int ord)
     return need == 8 ? 8 : grid_nb(ord);
 }
 
+// (The fields and the `images == 0` branch of the packed-Cholesky family are DEAD since round 5 -- blob_images never returns 0
+// -- and stay on purpose: fac_layout is evaluated inside every kernel with a run-time `images`, and without the branch the
+// compiler allocates the registers of the C2 loop kernel differently: same source otherwise, 15 450 instead of 15 788
+// instructions, and 0.473 instead of 0.468 ms on the same box (profiles/r05z_ab_r04.txt).  Tidiness is not worth 1 %.)
 struct FacLayout {
+    // family (b): dead, see above
+    size_t L, dinvL, Zp, R, Yh, V, L11, dinv11, r1, T;
+    // family (a)
     size_t Kneg, MT, NTn, W, S11i, Rg, Rw, Rm;
     size_t scal, prof;
     size_t total;
-    int images;   // bit mask of the R images present (1 Rg, 2 Rw, 4 Rm)
+    int images;   // 0: family (b); else bit mask of the R images present (1 Rg, 2 Rw, 4 Rm)
     int nbw;      // 8x8-grid blocks of 8 for m (0 = n/a)
     int nbg;      // grid blocks of 16 for m
     int nba;      // grid blocks of 16 for the augmented order n+q+m (0 = family (a) unavailable)
@@ -112,21 +119,38 @@ QPX_LAYOUT_HD FacLayout fac_layout(int n, int m, int q, int images)
     FacLayout f;
     size_t o = 0;
     f.images = images;
+    f.L = f.dinvL = f.Zp = f.R = f.Yh = f.V = f.L11 = f.dinv11 = f.r1 = f.T = 0;
     f.Kneg = f.MT = f.NTn = f.W = f.S11i = f.Rg = f.Rw = f.Rm = 0;
-    f.nba = grid_nb(n + q + m);
-    f.nbg = grid_nb(m);
-    f.nbw = wave_nb(m);
-    f.nbt = tile_nb(m);
-    f.Kneg = o; o += align4((size_t)n * n);
-    f.MT = o;   o += align4((size_t)n * m);
-    f.NTn = o;  o += align4((size_t)q * n);
-    f.W = o;    o += align4((size_t)m * q);
-    f.S11i = o; o += align4((size_t)q * q);
-    f.scal = o; o += 4;
-    f.prof = o; o += 8;
-    f.Rg = o;   if (images & 1) o += (size_t)(f.nbg * (f.nbg + 1) / 2) * 256;
-    f.Rw = o;   if ((images & 2) && f.nbw > 0) o += (size_t)(f.nbw * (f.nbw + 1) / 2) * 64;
-    f.Rm = o;   if ((images & 4) && f.nbt > 0) o += tile_image_elems(f.nbt);
+    f.nbw = f.nbg = f.nba = f.nbt = 0;
+    if (images == 0) {
+        f.L = o;      o += align4(tri((size_t)n));
+        f.dinvL = o;  o += align4(n);
+        f.Zp = o;     o += align4((size_t)n * m);
+        f.R = o;      o += align4(tri((size_t)m));
+        f.Yh = o;     o += align4((size_t)n * q);
+        f.V = o;      o += align4((size_t)q * m);
+        f.L11 = o;    o += align4(tri((size_t)q));
+        f.dinv11 = o; o += align4(q);
+        f.r1 = o;     o += align4(m);
+        f.scal = o;   o += 4;
+        f.prof = o;   o += 8;
+        f.T = o;      o += align4(tri((size_t)m));
+    } else {
+        f.nba = grid_nb(n + q + m);
+        f.nbg = grid_nb(m);
+        f.nbw = wave_nb(m);
+        f.nbt = tile_nb(m);
+        f.Kneg = o; o += align4((size_t)n * n);
+        f.MT = o;   o += align4((size_t)n * m);
+        f.NTn = o;  o += align4((size_t)q * n);
+        f.W = o;    o += align4((size_t)m * q);
+        f.S11i = o; o += align4((size_t)q * q);
+        f.scal = o; o += 4;
+        f.prof = o; o += 8;
+        f.Rg = o;   if (images & 1) o += (size_t)(f.nbg * (f.nbg + 1) / 2) * 256;
+        f.Rw = o;   if ((images & 2) && f.nbw > 0) o += (size_t)(f.nbw * (f.nbw + 1) / 2) * 64;
+        f.Rm = o;   if ((images & 4) && f.nbt > 0) o += tile_image_elems(f.nbt);
+    }
     f.total = o;
     return f;
 }

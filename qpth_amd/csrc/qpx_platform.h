@@ -12,9 +12,6 @@
 
 #define QPX_DEV __device__ __forceinline__
 #define QPX_HD __host__ __device__ __forceinline__
-// a device function that keeps its own register allocation (called, not inlined): the one-wave vector phases that ride in the
-// sixteen-wave substitution kernel hold 7 x 8 doubles per lane -- inlined, they pushed the 128-register kernel into scratch
-#define QPX_DEV_CALL __device__ __noinline__
 // keep the compiler's scheduler from moving instructions across this point (order of MFMA groups and LDS writes)
 #ifndef QPX_SCHED_FENCE
 #define QPX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

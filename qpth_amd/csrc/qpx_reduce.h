@@ -123,7 +123,7 @@ template <class T> QPX_DEV void batch_outer_sum_body(const Block& b, const Outer
 // x = M^-1 r for one general k x k system per workgroup (Gaussian elimination with partial pivoting, M and r in global
 // memory, both overwritten: r by x).  The one user: factor_solve_kkt_reg with equality constraints (batch.py:273-310), whose
 // -eps I in the (y, y) block is a rank-neq correction of the condensed system -- (I + eps Y) dy = dy0 with Y = d(dy)/d(ry)
-// -- a neq x neq system per QP that rounds 4 handed to torch.linalg.solve.  Off the QPFunction path and small: one pivot
+// -- a neq x neq system per QP that round 4 handed to a library solve on the host side.  Off the QPFunction path and small: one pivot
 // per pair of barriers, the trailing update dealt over the 256 threads.
 template <class T> struct DenseSolveArgs {
     int B, k;

@@ -25,7 +25,6 @@
 
 #define QPX_DEV inline
 #define QPX_HD inline
-#define QPX_DEV_CALL inline
 #define QPX_SCHED_FENCE() ((void)0)
 #define QPX_LAUNDER_V(x) ((void)0)
 #define QPX_LAUNDER_S(x) ((void)0)
