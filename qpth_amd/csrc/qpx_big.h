@@ -31,7 +31,7 @@ constexpr int kBB = 64;          // block order
 // (round 4) Every matrix of the blob is stored BLOCK by BLOCK: block (rb, cb) of a matrix with `ld` elements per row is
 // the 4096 contiguous elements at ((rb * (ld / 64)) + cb) * 4096, row-major inside.  A workgroup that reads a 64 x 64
 // block -- every GEMM operand, every substitution step -- then reads 32 KB of consecutive memory instead of 64 pieces of
-// 512 bytes a matrix row apart: the family is HBM-bound (profiles/r04c_c4_pmc_*: the whole pass moves 1.9 GB at an
+// 512 bytes a matrix row apart: the family is HBM-bound (profiles/archive/r04c_c4_pmc_*: the whole pass moves 1.9 GB at an
 // effective 3.5 TB/s), and the DRAM pages like the long runs better.
 constexpr int kBE = kBB * kBB;   // elements of a block
 QPX_LAYOUT_HD size_t big_blk(int ld, int rb, int cb) { return ((size_t)rb * (ld / kBB) + cb) * kBE; }
@@ -441,7 +441,7 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
     const int nch = a.nk * (kBB / kGC);
     // (one chunk of operands in flight per thread.  Two measured 5 % SLOWER at C4 with the C tile still fetched up front
     // -- four spilled registers at the 128-register limit of four workgroups per CU -- and EQUAL with the C tile fetched
-    // after the k-loop instead (114 registers, no spill): the launches are not waiting for their operands.  profiles/r04j, r04k.)
+    // after the k-loop instead (114 registers, no spill): the launches are not waiting for their operands.  profiles/archive/r04j, r04k.)
     T pa[4], pb[4];
     auto fetch = [&](int ch) {
         const int kb = ch >> 2, ko = (ch & 3) * kGC;                           // k-block, offset of the chunk inside it

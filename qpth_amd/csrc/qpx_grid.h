@@ -482,7 +482,7 @@ QPX_DEV int sweep_step(const Block& blk, const GridPos<16>& g, T (&E)[gtri(NBL)]
 //   E_ij -= (C P^-1 C^T)_ij  for i, j outside the block,   E_i,P = (C P^-1)_i,   E_PP = -P^-1,     C = columns k0 .. k0+3
 // -- exactly what four rank-1 steps compose to, with two barriers and one serial chain (publish -> barrier -> reciprocals)
 // per four pivots instead of four: one pivot of the rank-1 form cost ~2 400 cycles with two QPs per CU, against ~830
-// for its 26 LDS reads and 91 FMAs per thread (profiles/r03a: the sweep was 74 % of the pre-factorisation).
+// for its 26 LDS reads and 91 FMAs per thread (profiles/archive/r03a: the sweep was 74 % of the pre-factorisation).
 //   A  the owners publish the four columns (from the LOWER triangle only, as the rank-1 step: column k0+t below its
 //      pivot, row k0+t left of it)                                                              -- barrier 1
 //   B  every thread sweeps the 4 x 4 block P in registers (-> -P^-1, the same arithmetic in every thread, so the
@@ -616,7 +616,7 @@ template <class T, int NBL, int KB> struct SweepBlocks {
         // are exposed.  Measured on one MI355X, pre-factorisation alone, rank-1 -> groups of four: C2 (NBL 13) 0.166 ->
         // 0.158 ms, C3 (NBL 10) 0.139 -> 0.123 ms; at NBL 8 with eight workgroups per CU (B = 2048, n = m = 64) the
         // other workgroups already hide those latencies and the groups' extra work (U, the assignments) costs 0.189 ->
-        // 0.196 ms: rank-1 stays there (profiles/r03w).
+        // 0.196 ms: rank-1 stays there (profiles/archive/r03w).
         if constexpr (NBL >= 10) {
 #pragma unroll 1
             for (int gq = 0; 4 * gq + 4 <= kend; ++gq) {
@@ -882,8 +882,8 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
     // and R 1 on the way; passes 0.. are the IPM iterations.  One loop so that the factorisation and
     // the solves are instantiated once (they are the bulk of the kernel's code).
     // (Re-loading R right after the last solve of the previous pass, so that the loads fly during the lead wave's
-    // vector work, was measured twice: no gain in round 2 -- profiles/r02b_panel_ab.txt, "late" -- and +3 % loop time
-    // with the chain-wave form, profiles/r03h_ab_loop_variants.txt.)
+    // vector work, was measured twice: no gain in round 2 -- profiles/archive/r02b_panel_ab.txt, "late" -- and +3 % loop time
+    // with the chain-wave form, profiles/archive/r03h_ab_loop_variants.txt.)
     int stop = 0;
     for (int it = -1; it < a.maxIter && !stop; ++it) {
         const bool first = it < 0;
@@ -1217,7 +1217,7 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
     // time, BEFORE the matrix is loaded: beside the tiles their 64 registers cost a workgroup per CU at four tile rows.
     auto products = [&](const T* rX, const T* rY, T* rH, T* oX) {
         // (eight in flight at up to four tile rows: sixteen made the kernel's register peak there, 142 -> 178, and cost
-        // the third workgroup per CU -- +1.4 % on the step at B = 8192, nz = nineq = 64, profiles/r04t)
+        // the third workgroup per CU -- +1.4 % on the step at B = 8192, nz = nineq = 64, profiles/archive/r04t)
         block_matTvec2<T, 1, 0, T, (M8 > 64 ? 16 : 8)>(b, rH, F + lay.MT, m, oX, F + lay.Kneg, n, rX, n);
         if (q > 0) {
             Mat::sync(b);

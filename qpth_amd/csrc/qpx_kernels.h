@@ -3,7 +3,7 @@
 //
 // (Rounds 1-4 also kept the round-1 WORKGROUP kernels here -- prefactor_body / ipm_body / kkt_body: one 256-thread workgroup
 // per QP, packed Cholesky factors and substitutions in LDS or in the blob -- reachable through knob 1 only since the
-// large-QP family took every size beyond the thread-grid / tile kernels in round 4 (3-6 x faster there, profiles/r04b).
+// large-QP family took every size beyond the thread-grid / tile kernels in round 4 (3-6 x faster there, profiles/archive/r04b).
 // Deleted in round 5; libqpx_hip_r04.so, archived beside the product, still holds them for A/Bs.)
 #pragma once
 #include "qpx_layout.h"

@@ -165,7 +165,7 @@ struct Block {
     template <int GK> QPX_DEV double grp_bcast(double v) const
     {
         static_assert(GK >= 0 && GK < 4, "four rows of 16 lanes");
-#ifndef QPX_GRP_BCAST_SWAPS          // ds_bpermute: two instructions; with the chain wave alone on its SIMD -1 % loop time (profiles/r03r)
+#ifndef QPX_GRP_BCAST_SWAPS          // ds_bpermute: two instructions; with the chain wave alone on its SIMD -1 % loop time (profiles/archive/r03r)
         return __shfl(v, GK * 16 + (lane() & 15), kWave);
 #else
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -207,11 +207,11 @@ struct Block {
         c[0] = acc[0]; c[1] = acc[1]; c[2] = acc[2]; c[3] = acc[3];
     }
     // c += FOUR independent 4x4x4 products (v_mfma_f64_4x4x4_4b_f64), one accumulator register.  Decoded on the part
-    // (scripts/probe_mfma4.py, profiles/r03y_mfma4_layout.txt): lane l = 16 h + 4 blk + j holds C_blk[h][j] and gives
+    // (scripts/probe_mfma4.py, profiles/archive/r03y_mfma4_layout.txt): lane l = 16 h + 4 blk + j holds C_blk[h][j] and gives
     // a = A_blk[j][h] (row j, k = h) and b = B_blk[h][j] (k = h, column j).  With the SAME A in all four blocks this is
     // rows 4 q .. 4 q + 3 of a 16 x 16 tile in the accumulator layout of the 16x16x4 form (register q, lane 16 h + c),
     // the B operand being register s of the other tile as it stands: the 16x16x4 product at four-row granularity
-    // (16.3 cycles per instruction, profiles/r03y_mfma_ubench.txt).
+    // (16.3 cycles per instruction, profiles/archive/r03y_mfma_ubench.txt).
     QPX_DEV void mfma4x4x4(double a, double b, double& c) const { c = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
     // the f32 form (v_mfma_f32_16x16x4_f32): same operands, but the accumulator layout differs -- lane
     // l holds c[r] = C[4 (l >> 4) + r][l & 15]

@@ -53,7 +53,7 @@ QPX_LAYOUT_HD bool prefac_tile_serves(int n, int m, int q, int images)
 inline void prefac_deal(int nbn, int n, int m, unsigned (&pf_k)[4], unsigned (&pf_r)[4])
 {
     const int nbm = (m + 15) >> 4, nbr = (n + 15) >> 4, cap = prefac_cap(nbn);
-    const int kextra = 1;          // a tile of K costs a little more than its products (its own loop, the mirrored stores); 0 .. 9 measured equal within noise (profiles/r04q)
+    const int kextra = 1;          // a tile of K costs a little more than its products (its own loop, the mirrored stores); 0 .. 9 measured equal within noise (profiles/archive/r04q)
     int L[4];
     auto pick = [&](int cost) {
         int ww = 3;
@@ -263,7 +263,7 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
     // four columns of a k-slice go to which lane group is free as long as the A operand follows, and this way a lane's
     // four values are 32 consecutive bytes (two 16-byte loads).  (With column 4 s + g every 128-byte line was touched by
     // four load instructions of the wave, and with eight waves' blocks thrashing a 16 KB L1 each touch came from the L2:
-    // the workgroup's memory pipeline was busy with G for ~10 k cycles, profiles/r04p.)
+    // the workgroup's memory pipeline was busy with G for ~10 k cycles, profiles/archive/r04p.)
     // (buffer loads from the block's first row: one lane offset for the 28 loads, rows beyond m read as zero; columns
     // beyond n are masked where the values are used, so that nothing waits for the loads here)
     auto load_g = [&](int i, T (&Gop)[NBN][4]) {

@@ -129,7 +129,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         // -- s_getreg HW_ID -- so that the chain waves of the two workgroups of a CU shared SIMD 0 and never sat beside
         // the other workgroup's MFMA streams; by wave index they land on different SIMDs, each beside one tile wave of
         // the other QP.  Same box, C2: 0.5349 vs 0.5327 ms -- no difference, so the simpler rule stays:
-        // profiles/r03a (placement probe), r03q (A/B).)
+        // profiles/archive/r03a (placement probe), r03q (A/B).)
         QPX_DEV void assign(const Block&, int*) {}
         // the wave that does the O(m) vector work of the interior-point loop
         QPX_DEV bool lead(const Block& blk) const { return CH ? chain : blk.wave() == 0; }
@@ -198,7 +198,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #define QPX_PIVOT_HEAD 2
 #endif
     // pivots of the next block the chain wave eliminates ahead of barrier Y (same box, C2 loop kernel: 0 -> 0.4749 ms,
-    // 2 -> 0.4709, 4 -> 0.4863, 6 -> 0.5010, 8 -> 0.5128: profiles/r03vb -- the wait it fills is two pivots long)
+    // 2 -> 0.4709, 4 -> 0.4863, 6 -> 0.5010, 8 -> 0.5128: profiles/archive/r03vb -- the wait it fills is two pivots long)
     static constexpr int kPivotHead = QPX_PIVOT_HEAD;
     // scratch: X (16 x XS: the 16 old rows of a panel) | S, W (16 x SS: pivot block, its inverse factor) | flag |
     // { part (NWM x NBL x 64) | red (NWM x NROW x 17) } or, during a factorisation, BT (NBL x 256: the operand
@@ -678,7 +678,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                 // four-row granularity with the four-block matrix instruction (v_mfma_f64_4x4x4_4b: register q of a tile
                 // += A_q B with the same B operands), and row blocks that are all padding get nothing -- their operand
                 // columns are zero.  (Everywhere else the 16x16x4 form stays: with full tiles the four-block form
-                // measured 6 % slower, profiles/r03x.)
+                // measured 6 % slower, profiles/archive/r03x.)
                 const int nq = mrows - 16 * I >= 16 ? 4 : (mrows - 16 * I <= 0 ? 0 : (mrows - 16 * I + 3) >> 2);
                 if (I > Ip && nq < 4) {
                     if (nq > 0) update_row_quads<PP, I>(blk, p, E, BT, nrd, Ip, skip, zr, nq);
@@ -928,7 +928,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                 if constexpr (kChain) {
                     if (la) {
                         // (two accumulators per product -- chains of two dependent MFMAs instead of four -- measured no
-                        // gain: this interval waits for the tile waves' operand tiles anyway, profiles/r03h)
+                        // gain: this interval waits for the tile waves' operand tiles anyway, profiles/archive/r03h)
                         const T* X = scr + kX;
                         T acc[4], bx[4], ao[4], sacc[4];
 #pragma unroll
@@ -1012,7 +1012,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // (A form of the chain-wave factorisation WITHOUT workgroup barriers between chain and tile waves -- LDS words
     // signalling "W_k is ready" one way and "the inputs of pivot block k are ready" the other, the tile waves keeping a
     // counter barrier of their own, so that the chain wave never waits for the operand tiles -- was built and measured
-    // in round 3: +7 % loop time (0.560 vs 0.523 ms at C2, profiles/r03s_ab_async_chain.txt).  The tile waves, not the
+    // in round 3: +7 % loop time (0.560 vs 0.523 ms at C2, profiles/archive/r03s_ab_async_chain.txt).  The tile waves, not the
     // chain wave, are the longer side of a panel (operand tiles + nine tile updates + publication ~ 4 700 cycles against
     // ~4 100 for pivot block + look-ahead), so taking the chain wave off their barriers buys nothing and the polling
     // costs a little.  Removed.)

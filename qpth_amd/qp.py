@@ -90,7 +90,7 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3,
                 if ctx.refine > 0:
                     # (the solves inside a finishing step are NOT refined: the step's own residuals are exact, and refining
                     # the directions as well changes nothing in the answer -- C2 / C3 float32, two steps: the same error
-                    # distribution to three digits -- for 40 % more time per step; profiles/r04f)
+                    # distribution to three digits -- for 40 % more time per step; profiles/archive/r04f)
                     res = fac.polish(p, h, b, res, steps=ctx.refine, refine=0)
                 # one small read-back: the reference raises here too (qp.py:81-85, batch.py:379-386)
                 fac.raise_on_failure(check_Q_spd)

@@ -4,7 +4,7 @@
 HBM bytes per launch of the PDIPM loop kernel = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; the factor 2 is the
 gfx950 correction of MI355X_MICROARCH.md, "HBM" -- calibrated in round 3 for the 8-byte-per-lane buffer loads the tile
 kernels use: 2 GiB streamed once reads FETCH_SIZE = 1.0486e6 KB with raw_buffer_load_b64 and with 16-byte global loads
-alike, profiles/r03a_probes_and_phases.txt).  The record carries the digest of the kernel sources it was
+alike, profiles/archive/r03a_probes_and_phases.txt).  The record carries the digest of the kernel sources it was
 measured on; bench.py reports `roofline.traffic` only when that digest is the running build's."""
 import json
 import os
@@ -40,7 +40,7 @@ def main():
            "fetch_size_kb": f_kb, "write_size_kb": w_kb, "launches": [nf, nw], "kernel": kname,
            "kernel_source_digest": kernel_source_digest(),
            "fetch_size_factor": 2.0,
-           "fetch_size_factor_source": "profiles/r03a_probes_and_phases.txt: 2 GiB streamed once by raw_buffer_load_b64 (8 B per lane) -> FETCH_SIZE 1048603 KB = 0.500 of the bytes; same for 16 B per lane",
+           "fetch_size_factor_source": "profiles/archive/r03a_probes_and_phases.txt: 2 GiB streamed once by raw_buffer_load_b64 (8 B per lane) -> FETCH_SIZE 1048603 KB = 0.500 of the bytes; same for 16 B per lane",
            "source": "%s, %s: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes" % (os.path.basename(fetch), os.path.basename(write))}
     print(json.dumps(rec, indent=1))
 
