@@ -854,6 +854,7 @@ template <class T> struct BigPhaseArgs {
     int *iters, *status;
     int q; const T* bq; long long sb;     // equality constraints: b (B, q)
     int split;                            // phase 2 without d = s/z (phase 7 has written it)
+    int symv_sum;                         // phase 2: R z' arrives as the symmetric mat-vec's slots (big_symv_body stage 0): summed here, in stage 1's order
     int io32;                             // T = double: p, h, b, lam, slack, best_resid, trace are float32 arrays (QPX_F32_WIDE)
 };
 
@@ -979,15 +980,26 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
         const int it = a.it;
         const T tsz = sc[bsTau] * sc[bsSigz];
         T pri2 = 0, szdot = 0;
+        // (R z')_i: the vector the mat-vec launch wrote, or -- one launch less per pass -- the slots of the symmetric mat-vec
+        // added here in the order its second stage adds them (element i = 64 k + lane lies in block row k)
+        const T* ws = F + L.pol;
+        const int nbm = L.MP / kBB;
+        auto rzp = [&](int k, int i) {
+            if (!a.symv_sum) return vB[i];
+            T sum = ws[(size_t)k * kBB + lane];
+            for (int I2 = k + 1; I2 < nbm; ++I2) sum += ws[((size_t)nbm + (size_t)I2 * nbm + k) * kBB + lane];
+            return sum;
+        };
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int i = k * kWave + lane;
             if (i < m) {
                 const T zk = vZ[i], sk = vS[i];
-                const T rz = sk - vC[i] - vB[i];
+                const T bi = rzp(k, i);
+                const T rz = sk - vC[i] - bi;
                 pri2 = fma_(rz, rz, pri2);
                 szdot = fma_(sk, zk, szdot);
-                vRH[i] = vC[i] + vB[i] + tsz * vR1[i];
+                vRH[i] = vC[i] + bi + tsz * vR1[i];
                 if (!a.split) {
                     const T rzk = rcp_(zk);
                     vRZ[i] = rzk;
