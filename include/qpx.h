@@ -115,9 +115,8 @@ int qpx_refine_supported(int dtype, int n, int m, int q);
  * -- that lost their A/Bs and were deleted.)
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
  * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
- * synchronisation), 0 = one part; bits 20..24 = initial stagger between the side streams in units of 16 us; bit 25 (v7; until then the
- * four-wave substitutions of round 3, retired) = a pair of panels in four launches (the order of rounds 2-4) instead of the
- * chain form's three; bit 26 = the mat-vec R z' in front of the factorisation
+ * synchronisation), 0 = one part; bits 20..24 = initial stagger between the side streams in units of 16 us; (bit 25 selected
+ * the four-wave substitutions of round 3 until v7: retired with them); bit 26 = the mat-vec R z' in front of the factorisation
  * in the caller's stream (the round-3 order) instead of beside it on a helper stream; bit 27 =
  * diagonal blocks eliminated by one wave (the round-3 form) instead of four in the chain-wave form; bit 28 = on the
  * thread grid; bit 29 = no XCD-aware tile order.

@@ -369,14 +369,6 @@ template <class T> struct BigGemmArgs {
     // (big_diag_block) as soon as its update is done: W block index fuse_k of W, failure bit as in BigPanelArgs
     int fuse, fuse_k, fail_bit, tile;
     T* W; size_t sW;
-    // (round 5) fuse == 2, the CHAIN form of a panel launch L(i, k) = X(i, k) W_kk^T: the workgroup of tile 0 -- L(k+1, k) --
-    // goes on with what only it can do next: S = Cd(k+1, k+1) (+ dg) - L(k+1, k) L(k+1, k)^T, its elimination -> W_{k+1,k+1}
-    // (W block fuse_k = k + 1), and P = W_{k+1,k+1} L(k+1, k), stored NEGATED in the free W^T slot in front of W_{k+1,k+1}:
-    // the next panel launch then needs no column update in front of it, [L(i, k), X(i, k+1)] [-P, W_{k+1,k+1}]^T is L(i, k+1).
-    const T* Cd; size_t sCd; int ldcd;
-    // k-blocks >= kx of the A operand come from Ax instead of A (same block coordinates): the first pair of a factorisation
-    // of T = R + diag(d) reads X(i, 1) from R and L(i, 0) from T.  kx <= 0: all from A
-    const T* Ax; size_t sAx; int ldax, kx;
     int no_swizzle;              // A/B: plain (qp, tile) grid instead of the XCD-aware one (launcher only)
     int transb;                  // Bm is given as [k][column] (the product is A Bm, not A Bm^T): rows bkb0.. of Bm, columns of block brb0 + tj (pipelined form only)
 };
@@ -417,8 +409,6 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
     T* Bs = lds + 2 * kBB * LD;
     // operand blocks of k-block kb: A (arb0 + ti, akb0 + kb); B (brb0 + tj, bkb0 + kb), or (bkb0 + kb, brb0 + tj) when given as [k][column]
     const T* Ag = a.A + (size_t)qp * a.sA + big_blk(a.lda, a.arb0 + ti, a.akb0);
-    const T* Axg = (a.kx > 0 && a.Ax) ? a.Ax + (size_t)qp * a.sAx + big_blk(a.ldax, a.arb0 + ti, a.akb0) : Ag;
-    const int kx = (a.kx > 0 && a.Ax) ? a.kx : (1 << 30);
     const T* Bg = a.Bm + (size_t)qp * a.sB + (a.transb ? big_blk(a.ldb, a.bkb0, a.brb0 + tj) : big_blk(a.ldb, a.brb0 + tj, a.bkb0));
     const size_t bstep = a.transb ? (size_t)(a.ldb / kBB) * kBE : (size_t)kBE;        // from one k-block of B to the next
     const int lane = b.lane(), w = b.uniform(b.wave()), g = lane >> 4, c16 = lane & 15;
@@ -445,11 +435,7 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
                         cs[x][y][r] = Cs[(qr + 16 * x + Block::mfma_row(T(0), g, r)) * kBB + qc + 16 * y + c16];
         }
     };
-    // (the 128-register kernel -- four workgroups per CU, every launch that eliminates no diagonal block -- fetches its C tile
-    // BEHIND the k-loop since round 5: up front it kept 32 registers live across the loop, and with the second A base of the
-    // chain form's panel launch the kernel spilled; the two orders had measured equal in round 4, profiles/archive/r04k.  The
-    // 256-register kernel of the trailing updates keeps the fetch in front, under its operand loads.)
-    if constexpr (kFuse) load_c();
+    load_c();
     // staging coordinates: A (and B as [column][k]): row sr, k 4 sq ..; B as [k][column]: k-row tr, columns 4 tq ..
     const int sr = b.tid >> 2, sq = b.tid & 3, tr = b.tid >> 4, tq = b.tid & 15;
     const int nch = a.nk * (kBB / kGC);
@@ -459,7 +445,7 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
     T pa[4], pb[4];
     auto fetch = [&](int ch) {
         const int kb = ch >> 2, ko = (ch & 3) * kGC;                           // k-block, offset of the chunk inside it
-        ld4((kb < kx ? Ag : Axg) + (size_t)kb * kBE + sr * kBB + ko + 4 * sq, pa);
+        ld4(Ag + (size_t)kb * kBE + sr * kBB + ko + 4 * sq, pa);
         if (a.transb) ld4(Bg + (size_t)kb * bstep + (ko + tr) * kBB + 4 * tq, pb);
         else ld4(Bg + (size_t)kb * bstep + sr * kBB + ko + 4 * sq, pb);
     };
@@ -489,7 +475,6 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
             b.mfma16x16x4(a1[s], b1[s], acc[1][1]);
         }
     }
-    if constexpr (!kFuse) load_c();
     const bool fused = kFuse && a.fuse && tile == 0; // uniform
     const bool mir = a.mirror && crb != ccb;         // uniform
     const bool staged = fused || mir;
@@ -518,84 +503,8 @@ template <class T, bool kFuse> QPX_DEV void big_gemm2_body(const Block& b, const
     if constexpr (kFuse) {
         if (fused) {
             int* ctrl = a.ctrl ? a.ctrl + (size_t)qp * a.sctrl : nullptr;
-            T* Wk = a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB;
-            if (a.fuse == 2) {
-                // ---- the chain form: the staged tile is L = L(k+1, k).  S = Cd(k+1, k+1) (+ dg) - L L^T on the matrix cores,
-                // operands straight from the staged tile (rows of L are both the A rows and the B rows; row stride kBL)
-                T s2[2][2][4];
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s2[x][y][r] = T(0);
-                for (int ko = 0; ko < kBB; ko += kGC) {
-                    T a0[4], a1[4], b0[4], b1[4];
-                    ld4(lds + (qr + c16) * kBL + ko + 4 * g, a0);
-                    ld4(lds + (qr + 16 + c16) * kBL + ko + 4 * g, a1);
-                    ld4(lds + (qc + c16) * kBL + ko + 4 * g, b0);
-                    ld4(lds + (qc + 16 + c16) * kBL + ko + 4 * g, b1);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        b.mfma16x16x4(a0[s], b0[s], s2[0][0]);
-                        b.mfma16x16x4(a0[s], b1[s], s2[0][1]);
-                        b.mfma16x16x4(a1[s], b0[s], s2[1][0]);
-                        b.mfma16x16x4(a1[s], b1[s], s2[1][1]);
-                    }
-                }
-                const T* Cd = a.Cd + (size_t)qp * a.sCd + big_blk(a.ldcd, a.fuse_k, a.fuse_k);
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int il = qr + 16 * x + Block::mfma_row(T(0), g, r), jl = qc + 16 * y + c16;
-                            T v = Cd[il * kBB + jl];
-                            if (a.dg && il == jl) v += a.dg[(size_t)qp * a.sdg + a.fuse_k * kBB + il];
-                            s2[x][y][r] = v - s2[x][y][r];
-                        }
-                b.sync();                            // every wave has read L out of the staged tile
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            lds[(qr + 16 * x + Block::mfma_row(T(0), g, r)) * kBL + qc + 16 * y + c16] = s2[x][y][r];
-                b.sync();
-            }
-            big_diag_block<T>(b, [&](int i, int j) { return lds[i * kBL + j]; }, Wk, ctrl, a.fail_bit, lds, lds + kBB * kBL, a.tile);
-            if (a.fuse == 2) {
-                // ---- -P = -W_{k+1,k+1} L(k+1, k) into the W^T slot in front of W_{k+1,k+1} (nobody reads W^T of this factor:
-                // kDiagNoWt).  W and L come back from global memory (this workgroup wrote both; L2): thread t forms the
-                // 4 x 4 outputs of rows 4 (t / 16) .., columns 4 (t % 16) ..; W is lower triangular
-                b.sync();
-                const int i0 = (b.tid >> 4) * 4, j0 = (b.tid & 15) * 4;
-                T pacc[4][4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) pacc[u][v] = T(0);
-                for (int c = 0; c < i0 + 4; ++c) {
-                    T lrow[4];
-                    ld4(C + c * kBB + j0, lrow);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const T wv = Wk[(i0 + u) * kBB + c];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) pacc[u][v] = fma_(wv, lrow[v], pacc[u][v]);
-                    }
-                }
-                T* Pn = Wk - kBB * kBB;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    T o[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) o[v] = -pacc[u][v];
-                    st4(Pn + (i0 + u) * kBB + j0, o);
-                }
-            }
+            big_diag_block<T>(b, [&](int i, int j) { return lds[i * kBL + j]; },
+                              a.W + (size_t)qp * a.sW + (size_t)a.fuse_k * 2 * kBB * kBB, ctrl, a.fail_bit, lds, lds + kBB * kBL, a.tile);
         }
     }
 }
@@ -945,7 +854,6 @@ template <class T> struct BigPhaseArgs {
     int *iters, *status;
     int q; const T* bq; long long sb;     // equality constraints: b (B, q)
     int split;                            // phase 2 without d = s/z (phase 7 has written it)
-    int symv_sum;                         // phase 2: R z' arrives as the symmetric mat-vec's slots (big_symv_body stage 0): summed here, in stage 1's order
     int io32;                             // T = double: p, h, b, lam, slack, best_resid, trace are float32 arrays (QPX_F32_WIDE)
 };
 
@@ -1071,26 +979,15 @@ template <class T, int NS> QPX_DEV void big_phase_body(const Block& b, const Big
         const int it = a.it;
         const T tsz = sc[bsTau] * sc[bsSigz];
         T pri2 = 0, szdot = 0;
-        // (R z')_i: the vector the mat-vec launch wrote, or -- one launch less per pass -- the slots of the symmetric mat-vec
-        // added here in the order its second stage adds them (element i = 64 k + lane lies in block row k)
-        const T* ws = F + L.pol;
-        const int nbm = L.MP / kBB;
-        auto rzp = [&](int k, int i) {
-            if (!a.symv_sum) return vB[i];
-            T sum = ws[(size_t)k * kBB + lane];
-            for (int I2 = k + 1; I2 < nbm; ++I2) sum += ws[((size_t)nbm + (size_t)I2 * nbm + k) * kBB + lane];
-            return sum;
-        };
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int i = k * kWave + lane;
             if (i < m) {
                 const T zk = vZ[i], sk = vS[i];
-                const T bi = rzp(k, i);
-                const T rz = sk - vC[i] - bi;
+                const T rz = sk - vC[i] - vB[i];
                 pri2 = fma_(rz, rz, pri2);
                 szdot = fma_(sk, zk, szdot);
-                vRH[i] = vC[i] + bi + tsz * vR1[i];
+                vRH[i] = vC[i] + vB[i] + tsz * vR1[i];
                 if (!a.split) {
                     const T rzk = rcp_(zk);
                     vRZ[i] = rzk;

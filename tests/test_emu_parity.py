@@ -476,10 +476,8 @@ def test_edge_shapes_match_the_reference(name):
                                               ((1, 66, 70, 0), torch.float64, 3 + (1 << 26)), ((2, 130, 200, 0), torch.float64, 3),
                                               ((2, 66, 70, 5), torch.float64, 3), ((1, 130, 40, 70), torch.float64, 3),
                                               ((2, 66, 70, 5), torch.float32, 3), ((2, 66, 70, 5), torch.float64, 3 + (2 << 16)),
-                                              # five and four blocks (odd / even: every branch of the pair loop), the chain form of a pair of panels (default) and,
-                                              # knob bit 25, the four-launch order it replaced
-                                              ((1, 130, 300, 0), torch.float64, 3), ((1, 130, 300, 0), torch.float64, 3 + (1 << 25)),
-                                              ((1, 250, 200, 10), torch.float64, 3), ((2, 66, 70, 5), torch.float64, 3 + (1 << 25)), ((1, 200, 130, 0), torch.float32, 3)])
+                                              # five and four blocks (odd / even: every branch of the loop over pairs of panels)
+                                              ((1, 130, 300, 0), torch.float64, 3), ((1, 250, 200, 10), torch.float64, 3), ((1, 200, 130, 0), torch.float32, 3)])
 def test_large_qp_family(shape, dtype, knob):
     """BASELINE.json configs[3] runs through a multi-kernel family (blocked Cholesky / triangular solves / MFMA trailing
     updates on 64 x 64 blocks, matrices in HBM).  Forced here (knob 3) at sizes of two and three blocks so that the
