@@ -1230,6 +1230,9 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
         Mat::sync(b);
     };
     products(vRX, vRY, vRH, vDX);
+    // (round 5 tried the image of R requested BEFORE the products at seven tile rows, where the registers allow it, so that its
+    // round trip to HBM runs under theirs: 1.5 us SLOWER at C2, 0.0499 vs 0.0485 ms, same box -- the image's 57 KB then
+    // compete with the 160 KB the products stream.  profiles/r05f_ab_symv_prefetch_and_backward_load_order.txt)
     typename Mat::Regs E;
     Mat::load(b, g, E, Mat::image(F, lay));
     Mat::add_diag(g, E, vD);

@@ -16,7 +16,9 @@ struct SidePool {
     // [kMaxSide, kPoolSlots): one helper stream per part (R z' beside the factorisation), part i -> kMaxSide + i
     hipStream_t s[kPoolSlots];
     hipEvent_t fork[kPoolSlots], done[kPoolSlots];
-    bool ok = false;
+    bool ok[kPoolSlots] = {};             // created on first use, slot by slot: a process holds the streams it uses (typically
+                                          // one: the second part, or the helper), not seven -- streams share the device's four
+                                          // hardware queues, and an idle stream that sits on the caller's queue serialises with it
 };
 constexpr int kMaxDev = 16;
 static thread_local SidePool g_side[kMaxDev];
@@ -33,13 +35,13 @@ int stream_fork(void* caller, int nside, void** side, int delay_us, int first)
     int dev = 0;
     if (nside < 1 || first < 0 || first + nside > kPoolSlots || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
     SidePool& p = g_side[dev];
-    if (!p.ok) {
-        for (int i = 0; i < kPoolSlots; ++i)
-            if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&p.fork[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) != hipSuccess)
-                return QPX_ERR_LAUNCH;
-        p.ok = true;
+    for (int i = first; i < first + nside; ++i) {
+        if (p.ok[i]) continue;
+        if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&p.fork[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) != hipSuccess)
+            return QPX_ERR_LAUNCH;
+        p.ok[i] = true;
     }
     // (one fork event per first slot: two parts of a batch fork their helper streams from different streams at once)
     if (hipEventRecord(p.fork[first], (hipStream_t)caller) != hipSuccess) return QPX_ERR_LAUNCH;
