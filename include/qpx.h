@@ -122,6 +122,8 @@ int qpx_refine_supported(int dtype, int n, int m, int q);
  * thread grid; bit 29 = no XCD-aware tile order.
  * The knob must not change between qpx_pre_factor and the calls that consume its factors (it selects the
  * layout of `factors` too: ask qpx_factor_elems after setting it).
+ * Bits and values the library does not decode (retired knobs) are dropped, not stored: qpx_get_ipm_variant returns what
+ * was understood, so set-then-get tells a script that its knob no longer exists.
  * Returns the previous value. */
 int qpx_set_ipm_variant(int variant);
 int qpx_get_ipm_variant(void);      /* the calling thread's current value */

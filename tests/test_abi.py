@@ -50,6 +50,14 @@ def test_hip_library_loads_and_answers_metadata(built):
     assert lib.dll.qpx_kernel_family(_lib.QPX_F64, 100, 100, 0) == _lib.FAMILY_TILE
     assert lib.dll.qpx_kernel_family(_lib.QPX_F64, 500, 500, 0) == _lib.FAMILY_BIG
     assert b"not supported" in lib.dll.qpx_strerror(-2)
+    # the A/B knob: retired bits and values are dropped (set-then-get shows a script that its knob no longer exists)
+    old = lib.dll.qpx_set_ipm_variant(3 | (2 << 16) | (1 << 25) | (1 << 30))
+    try:
+        assert lib.dll.qpx_get_ipm_variant() == 3 | (2 << 16)
+        lib.dll.qpx_set_ipm_variant(1)                   # the workgroup kernels of round 1: deleted in v7
+        assert lib.dll.qpx_get_ipm_variant() == 0
+    finally:
+        lib.dll.qpx_set_ipm_variant(old)
 
 
 def test_hip_library_contains_gfx950_code(built):
