@@ -1013,3 +1013,37 @@ def test_edge_shapes_match_the_reference(dev, name):
     for k, gr in zip(("dQ", "dp", "dG", "dh", "dA", "db"), grads):
         if k in g and gr is not None and not ("dup" in name and k in ("dG", "dh")):
             assert np.abs(gr - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max()), k
+
+
+@pytest.mark.parametrize("B,n,m,q", [(64, 100, 100, 0), (32, 100, 50, 10), (24, 300, 200, 20), (128, 260, 260, 0)])
+def test_launch_sequence_replays_from_a_captured_graph(dev, B, n, m, q):
+    """The boundary is stream-ordered (include/qpx.h: every entry point enqueues on the caller's stream and returns; the
+    large-QP family forks and joins its side streams with events): the launch sequence of pre-factorisation + PDIPM loop +
+    backward is captured into ONE hipGraph and replayed on new data in the same buffers.  Asserted: the replay is bit-identical
+    to the eager calls on the same data (same kernels, same order), for the tile kernels, the thread grid with equality
+    constraints, the large-QP family with one part and with two parts on two streams (B >= 96)."""
+    from qpth_amd.kkt import KKTFactors
+    first = to_dev(problems.prof_qp(B, n, m, q, seed=21), dev, grad=False)
+    second = to_dev(problems.prof_qp(B, n, m, q, seed=22), dev, grad=False)
+    ones = torch.ones(B, n, dtype=torch.float64, device=dev)
+
+    def run(Q, p, G, h, A, b):
+        fac = KKTFactors.build(Q, G, A)
+        res = fac.ipm(p, h, b)
+        grads = fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones)
+        return [res.zhat, res.lam, res.slacks, res.iters, res.status] + [g for g in grads if g is not None]
+
+    eager = [[t.clone() for t in run(*data)] for data in (first, second)]       # (also the warm-up: LDS opt-ins, side streams)
+    torch.cuda.synchronize()
+    static = [t.clone() for t in first]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = run(*static)
+    for data, want in ((first, eager[0]), (second, eager[1]), (first, eager[0])):
+        for s, t in zip(static, data):
+            s.copy_(t)
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, exp in zip(outs, want):
+            assert torch.equal(got, exp), (B, n, m, q)
+    assert int(outs[4].max().item()) & 7 == 0
