@@ -10,12 +10,15 @@
 namespace qpx {
 
 // One pool of side streams + events per (host thread, device), created on first use and kept for the life of the
-// thread.  Fork / join are event record + stream wait: stream-ordered, legal under stream capture, no host sync.
+// thread.  Fork / join are event record + stream wait: stream-ordered, legal under stream capture, no host sync (the one
+// wait of the library is the check of a new side stream against the caller's, side_slot below).
 struct SidePool {
     // [0, kMaxSide): the streams of the parts of a batch beyond the first (which runs on the caller's);
     // [kMaxSide, kPoolSlots): one helper stream per part (R z' beside the factorisation), part i -> kMaxSide + i
     hipStream_t s[kPoolSlots];
     hipEvent_t fork[kPoolSlots], done[kPoolSlots];
+    void* beside[kPoolSlots] = {};        // the caller's stream a slot was last checked against (runs_beside)
+    bool checked[kPoolSlots] = {};
     bool ok[kPoolSlots] = {};             // created on first use, slot by slot: a process holds the streams it uses (typically
                                           // one: the second part, or the helper), not seven -- streams share the device's four
                                           // hardware queues, and an idle stream that sits on the caller's queue serialises with it
@@ -30,19 +33,68 @@ __global__ void k_stream_delay(long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
-int stream_fork(void* caller, int nside, void** side, int delay_us, int first)
+// HIP deals streams to the device's (four) hardware queues by a policy the API does not expose.  A side stream that lands on
+// the CALLER's queue does not run beside it: the two parts of a batch then execute one after the other -- twice the latency
+// chain of one part, 24.9 instead of 11.5 ms per step at C4 in a process that had used six other streams before
+// (profiles/r05p_stream_clash.txt).  So a slot is CHECKED once against the caller's stream it is used with (and again when that
+// stream changes): one 100-us delay kernel on each of the two streams between two timed events -- ~0.1 ms if they run side by
+// side, ~0.2 ms if they share a queue.  That is the one place where the library waits on the host (~0.3 ms, once per host thread,
+// device and caller stream); it is skipped while the caller's stream is being captured into a graph.
+static bool runs_beside(hipStream_t caller, hipStream_t side)
 {
-    int dev = 0;
-    if (nside < 1 || first < 0 || first + nside > kPoolSlots || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
-    SidePool& p = g_side[dev];
-    for (int i = first; i < first + nside; ++i) {
-        if (p.ok[i]) continue;
+    hipEvent_t e0, e1, es;
+    if (hipEventCreate(&e0) != hipSuccess) return true;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return true; }
+    if (hipEventCreateWithFlags(&es, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return true; }
+    float ms = 0.f;
+    bool ok = hipEventRecord(e0, caller) == hipSuccess && hipStreamWaitEvent(side, e0, 0) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, side, 100LL * 100);
+        hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, caller, 100LL * 100);
+        ok = hipEventRecord(es, side) == hipSuccess && hipStreamWaitEvent(caller, es, 0) == hipSuccess &&
+             hipEventRecord(e1, caller) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(es);
+    return !ok || ms < 0.16f;             // (a failed measurement decides nothing)
+}
+
+// make slot i of the pool a stream that runs beside `caller`: up to four candidates (one per hardware queue); the rejected ones
+// stay alive until the choice is made, so that the next candidate is dealt another queue
+static int side_slot(SidePool& p, int i, hipStream_t caller)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(caller, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!p.ok[i]) {
         if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&p.fork[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) != hipSuccess)
             return QPX_ERR_LAUNCH;
         p.ok[i] = true;
+        p.checked[i] = false;
     }
+    if (capturing || (p.checked[i] && p.beside[i] == (void*)caller)) return QPX_OK;
+    hipStream_t rejected[3];
+    int nrej = 0;
+    while (!runs_beside(caller, p.s[i]) && nrej < 3) {
+        hipStream_t next;
+        if (hipStreamCreateWithFlags(&next, hipStreamNonBlocking) != hipSuccess) break;
+        rejected[nrej++] = p.s[i];
+        p.s[i] = next;
+    }
+    for (int r = 0; r < nrej; ++r) (void)hipStreamDestroy(rejected[r]);
+    p.checked[i] = true;
+    p.beside[i] = (void*)caller;
+    return QPX_OK;
+}
+
+int stream_fork(void* caller, int nside, void** side, int delay_us, int first)
+{
+    int dev = 0;
+    if (nside < 1 || first < 0 || first + nside > kPoolSlots || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return QPX_ERR_LAUNCH;
+    SidePool& p = g_side[dev];
+    for (int i = first; i < first + nside; ++i)
+        if (const int e = side_slot(p, i, (hipStream_t)caller)) return e;
     // (one fork event per first slot: two parts of a batch fork their helper streams from different streams at once)
     if (hipEventRecord(p.fork[first], (hipStream_t)caller) != hipSuccess) return QPX_ERR_LAUNCH;
     for (int i = 0; i < nside; ++i) {

@@ -53,7 +53,8 @@ template <class T> int launch_big_polish(const BigPolishArgs<T>& a, void* stream
 // Side streams for the parts of a batch the large-QP family works on concurrently (qpx_api.inc: big_split).
 // stream_fork: side[0 .. nside) = streams of the calling host thread's pool, made to wait (event) for everything
 // enqueued on `caller` so far; stream_join: `caller` waits (events) for everything enqueued on them.  Neither
-// synchronises the host.  delay_us > 0: side stream i first sleeps i * delay_us (one idle wave), which sets the
+// synchronises the host -- except that stream_fork checks a side stream ONCE per caller stream (outside stream capture) for
+// running beside it and not on its hardware queue (qpx_hip_api.hip: side_slot, ~0.3 ms).  delay_us > 0: side stream i first sleeps i * delay_us (one idle wave), which sets the
 // parts out of phase with each other.
 // `first`: pool slot of side[0] -- [0, kMaxSide) are the parts' streams, kMaxSide + i the helper stream of part i's loop.
 int stream_fork(void* caller, int nside, void** side, int delay_us, int first = 0);

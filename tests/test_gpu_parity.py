@@ -1047,3 +1047,35 @@ def test_launch_sequence_replays_from_a_captured_graph(dev, B, n, m, q):
         for got, exp in zip(outs, want):
             assert torch.equal(got, exp), (B, n, m, q)
     assert int(outs[4].max().item()) & 7 == 0
+
+
+def test_large_qp_parts_on_a_caller_stream_among_many(dev):
+    """The large-QP family runs a batch of >= 96 QPs as two parts, the second on a side stream of its own.  HIP deals streams to
+    four hardware queues; the library checks once per caller stream that its side stream runs beside it and takes another one
+    otherwise (qpx_hip_api.hip: runs_beside; profiles/r05p_stream_clash.txt).  Here: the same batch on torch's default stream and
+    on streams created after several others had been used -- identical results whichever side stream was picked."""
+    from qpth_amd.kkt import KKTFactors
+    B, n, m = 96, 260, 260
+    Q, p, G, h, A, b = to_dev(problems.prof_qp(B, n, m, 0, seed=23), dev, grad=False)
+
+    def run():
+        fac = KKTFactors.build(Q, G, A)
+        res = fac.ipm(p, h, b)
+        return res.zhat.clone(), res.lam.clone(), res.iters.clone()
+
+    want = run()
+    torch.cuda.synchronize()
+    others = []
+    for k in range(7):
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            torch.zeros(1024, device=dev).add_(1.0)
+        others.append(st)
+        caller = torch.cuda.Stream(dev)
+        caller.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(caller):
+            got = run()
+        caller.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g, w), k
+    assert int(want[2].max().item()) > 0
