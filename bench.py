@@ -10,6 +10,10 @@ the measurement of SURVEY.md section 8d / prof-linear.py:110-118, device-synchro
 prof-linear.py:99.  Default workload = BASELINE.json configs[1] extended with the backward pass as its `metric`
 asks: batch=512, nz=100, nineq=100, neq=0, float64 (the dtype the 1e-4 parity gate holds in).
 
+Before the W warm-up steps the script runs --spin-up seconds (default 0.5) of the same step, untimed: the first GPU work of a
+fresh box runs ~7 % slower for its first few hundred steps (774 K against 831 K QPs/s, profiles/r05v_spin_up.txt); the timed
+region is exactly K steps either way (`untimed_spin_up_s` in the JSON line; --spin-up 0 turns it off).
+
 Multi-GPU (one process per GPU, RCCL):
   --config c2 (default)  every rank solves its own 512-QP shard and the ranks all_gather zhat (the only exchange
                          the path has, north_star / SURVEY 8e) inside the timed region  => "scaling": "weak"
@@ -267,6 +271,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spin-up", type=float, default=0.5, help="seconds of untimed steps in front of the warm-up steps (0 = none)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "custom"],
                     help="c2: B=512 nz=100 nineq=100 per GPU (default, weak scaling); c3: B=512 nz=100 nineq=50 "
                          "neq=10 per GPU; c4: B=128 nz=nineq=500 per GPU; c5: fixed GLOBAL batch 65536, nz=nineq=64 "
@@ -363,6 +368,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed: the device's clocks and the allocator settle (a fresh process' first few hundred steps run 1-2 % slower than its
+    # later ones: profiles/r05v_spin_up.txt); the warm-up proper follows.  The timed region is exactly `steps` steps.
+    spin_until = time.perf_counter() + args.spin_up
+    while True:
+        go = time.perf_counter() < spin_until
+        if distributed:              # (a step holds collectives at N > 1: every rank must run the same number of them)
+            flag = torch.tensor([1.0 if go else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            go = bool(flag.item() > 0)
+        if not go:
+            break
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -520,7 +539,7 @@ def main():
             "metric": "QPs/sec (fwd+bwd) at batch=512 nz=100 nineq=100; 1/2/4/8 MI355X",
             "value": value, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": arith, "data": "synthetic",
+            "vs_baseline": None, "dtype": arith, "data": "synthetic", "untimed_spin_up_s": args.spin_up,
             "config": {"workload": "%s fwd+bwd: batch=%d nz=%d nineq=%d neq=%d %s, dense random QP (prof-linear.py "
                                    "generator)%s, QPFunction(verbose=-1%s) defaults, p requires grad%s"
                                    % (names[args.config], Bcfg, n, m, q, "GLOBAL (sharded)" if strong else "per GPU",
