@@ -12,7 +12,12 @@ asks: batch=512, nz=100, nineq=100, neq=0, float64 (the dtype the 1e-4 parity ga
 
 Before the W warm-up steps the script runs --spin-up seconds (default 0.5) of the same step, untimed: the first GPU work of a
 fresh box runs ~7 % slower for its first few hundred steps (774 K against 831 K QPs/s, profiles/r05v_spin_up.txt); the timed
-region is exactly K steps either way (`untimed_spin_up_s` in the JSON line; --spin-up 0 turns it off).
+region is exactly K steps either way (`untimed_spin_up_s` in the JSON line; --spin-up 0 turns it off).  So that rounds stay
+comparable the line also carries the number of the protocol of rounds 1-4 from the same process: W warm-up steps, then 20
+timed steps, BEFORE the spin-up (`first_20_steps_qps`), and where the wall time of the run went (`wall_s`).
+
+QPX_FORCE_DIST=1 takes the N > 1 branch (RCCL process group, zhat all_gathered beside the backward, the C5 point) with
+WORLD_SIZE = 1: the collective code path on the one GPU of a box (tests/test_gpu_dist.py).
 
 Multi-GPU (one process per GPU, RCCL):
   --config c2 (default)  every rank solves its own 512-QP shard and the ranks all_gather zhat (the only exchange
@@ -203,16 +208,8 @@ def c5_point(rank, world, dev, dtype, barrier, steps=5, warmup=2):
     GB, n, m = 65536, 64, 64
     lo, hi = qdist.shard_bounds(GB, rank, world)
     B = hi - lo
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1000 + rank)
-    L = torch.rand(B, n, n, dtype=dtype, device=dev, generator=gen)
-    Q = L @ L.transpose(1, 2) + 1e-3 * torch.eye(n, dtype=dtype, device=dev)
-    del L
-    G = torch.randn(B, m, n, dtype=dtype, device=dev, generator=gen)
-    z0 = torch.randn(B, n, dtype=dtype, device=dev, generator=gen)
-    h = torch.bmm(G, z0.unsqueeze(2)).squeeze(2) + torch.rand(B, m, dtype=dtype, device=dev, generator=gen)
-    p = torch.randn(B, n, dtype=dtype, device=dev, generator=gen).requires_grad_(True)
-    e = torch.empty(0, dtype=dtype, device=dev)
+    Q, p, G, h, e, _ = device_batch(B, n, m, dev, dtype, 1000 + rank)
+    p.requires_grad_(True)
     ones = torch.ones(B, n, dtype=dtype, device=dev)
     qpf = QPFunction(verbose=-1)
 
@@ -239,11 +236,30 @@ def c5_point(rank, world, dev, dtype, barrier, steps=5, warmup=2):
             "data": "synthetic, generated on the device"}
 
 
-def side_config(dev, B, n, m, q, steps, warmup):
+def device_batch(B, n, m, dev, dtype, seed):
+    """prof-linear.py:64-75's generator in torch on the device (neq = 0): 65 536 QPs of C5 are 4.3 GB of Q and G, which the
+    numpy generator + H2D copy would spend half a minute on"""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    L = torch.rand(B, n, n, dtype=dtype, device=dev, generator=gen)
+    Q = L @ L.transpose(1, 2) + 1e-3 * torch.eye(n, dtype=dtype, device=dev)
+    del L
+    G = torch.randn(B, m, n, dtype=dtype, device=dev, generator=gen)
+    z0 = torch.randn(B, n, dtype=dtype, device=dev, generator=gen)
+    h = torch.bmm(G, z0.unsqueeze(2)).squeeze(2) + torch.rand(B, m, dtype=dtype, device=dev, generator=gen)
+    p = torch.randn(B, n, dtype=dtype, device=dev, generator=gen)
+    e = torch.empty(0, dtype=dtype, device=dev)
+    return Q, p, G, h, e, e
+
+
+def side_config(dev, B, n, m, q, steps, warmup, on_device=False):
     """One of BASELINE.json's other configurations timed the same way as the headline (K steps of fwd+bwd bracketed by
     synchronize, float64, p requires grad), after the headline's timed region -- so that the record of the default
     command (the one the driver runs) also holds C3 and C4, which were builder-run numbers only until round 5."""
-    _, (tQ, tp, tG, th, tA, tb) = make_batch(B, n, m, q, 0, np.float64, dev)
+    if on_device:
+        tQ, tp, tG, th, tA, tb = device_batch(B, n, m, dev, torch.float64, 1000)
+    else:
+        _, (tQ, tp, tG, th, tA, tb) = make_batch(B, n, m, q, 0, np.float64, dev)
     tp.requires_grad_(True)
     ones = torch.ones(B, n, dtype=tQ.dtype, device=dev)
     qpf = QPFunction(verbose=-1)
@@ -292,6 +308,9 @@ def main():
                          "finishing iterations on the residuals of the original data.  float64: default 0")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="default command only: do not time BASELINE.json's C3 and C4 behind the headline (extra.other_baseline_configs)")
+    ap.add_argument("--step-kernels-only", action="store_true",
+                    help="profiling runs: skip the launches a step does not contain (the loop with early stopping off, the backward "
+                         "with every gradient, the forward under no_grad), so that per-kernel averages and PMC sums are the step's")
     ap.add_argument("--table", default=None, choices=["prof-linear", "prof-gurobi"])
     args = ap.parse_args()
 
@@ -302,10 +321,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to time.")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    t_start = time.perf_counter()
+    wall = {}
+    distributed = world > 1 or os.environ.get("QPX_FORCE_DIST", "") == "1"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     if os.environ.get("QPX_VARIANT"):            # A/B knob for kernel development (include/qpx.h)
@@ -368,8 +390,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: the device's clocks and the allocator settle (a fresh process' first few hundred steps run 1-2 % slower than its
-    # later ones: profiles/r05v_spin_up.txt); the warm-up proper follows.  The timed region is exactly `steps` steps.
+    # the protocol of rounds 1-4, kept so that rounds stay comparable: W warm-up steps, then 20 timed steps, as the process'
+    # first GPU work (un-spun)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    u0 = time.perf_counter()
+    for _ in range(20):
+        step()
+    barrier()
+    first20 = time.perf_counter() - u0
+    if distributed:
+        tt = torch.tensor([first20], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        first20 = float(tt.item())
+    wall["setup_and_first_20_steps"] = time.perf_counter() - t_start
+    # untimed: the device's clocks and the allocator settle (a fresh box runs its first few hundred steps up to 7 % slower than
+    # its later ones: 774 K against 831 K QPs/s in profiles/r05v_spin_up.txt; 1-2 % in a process on a box that has already
+    # worked); the warm-up proper follows.  The timed region is exactly `steps` steps.
+    w0 = time.perf_counter()
     spin_until = time.perf_counter() + args.spin_up
     while True:
         go = time.perf_counter() < spin_until
@@ -385,11 +424,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    wall["spin_up_and_warmup"] = time.perf_counter() - w0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    wall["timed_region"] = dt
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -399,6 +440,7 @@ def main():
 
     # median over chunks of 10 steps: the box-to-box and run-to-run spread the single total hides (every rank
     # runs them: a step contains collectives at N > 1)
+    w0 = time.perf_counter()
     chunk_ms = []
     for _ in range(min(10, max(3, args.steps // 10))):
         barrier()
@@ -411,13 +453,20 @@ def main():
     # N > 1 on the default configuration: the line ALSO carries the north star's strong-scaling point (BASELINE.json
     # configs[4]: C5, fixed GLOBAL batch 65 536, nz = nineq = 64, contiguous slices, zhat all_gathered), so that whichever
     # command the driver runs at N = 1, 2, 4, 8 the record holds both readings of the metric.  Every rank takes part.
+    wall["median_chunks"] = time.perf_counter() - w0
+    w0 = time.perf_counter()
     extra = None
     if distributed and args.config == "c2" and not args.shared and all(v is None for v in (args.batch, args.nz, args.nineq, args.neq)):
         extra = {"c5_strong_scaling": c5_point(rank, world, dev, tQ.dtype, barrier)}
     if (not distributed and args.config == "c2" and not args.shared and args.dtype == "f64" and args.refine is None
             and not args.no_side_configs and all(v is None for v in (args.batch, args.nz, args.nineq, args.neq))):
+        # every BASELINE.json configuration that fits one GPU behind the headline, so that the driver's record holds them:
+        # C3, C4 and -- round 6 -- C5's 65 536 QPs on this one GPU (the point the 1/2/4/8 curve starts from)
         extra = {"other_baseline_configs": {"c3": side_config(dev, 512, 100, 50, 10, 100, 10),
-                                            "c4": side_config(dev, 128, 500, 500, 0, 10, 2)}}
+                                            "c4": side_config(dev, 128, 500, 500, 0, 10, 2),
+                                            "c5_one_gpu": side_config(dev, 65536, 64, 64, 0, 5, 2, on_device=True)}}
+    wall["side_configs"] = time.perf_counter() - w0
+    w0 = time.perf_counter()
 
     # float32 data at a size the float64 tile kernels serve runs in float64 arithmetic (QPFunction(refine=None),
     # QPX_F32_WIDE): the kernels timed and priced below are then the float64 ones, reading and writing float32 tensors
@@ -438,13 +487,15 @@ def main():
         t_ipm = time_launches(lambda: fac.ipm(kp, kh, kb), nrep)
         want_p = (False, True, False, False, False, False)
         t_bwd = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones_k, want=want_p), nrep)
-        t_bwd_all = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones_k), nrep)
-        set_stall_policy(_lib.STALL_OFF)
-        t_ipm_fixed = time_launches(lambda: fac.ipm(kp, kh, kb), max(3, nrep // 3))
-        set_stall_policy(None)
-        # forward only = BASELINE.json configs[1] as written (QPFunction forward, no backward), on the caller's tensors
-        with torch.no_grad():
-            t_fwd = time_launches(lambda: qpf(tQ.detach(), tp.detach(), tG.detach(), th, tA.detach() if q else tA, tb), nrep)
+        t_bwd_all = t_ipm_fixed = t_fwd = None
+        if not args.step_kernels_only:
+            t_bwd_all = time_launches(lambda: fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones_k), nrep)
+            set_stall_policy(_lib.STALL_OFF)
+            t_ipm_fixed = time_launches(lambda: fac.ipm(kp, kh, kb), max(3, nrep // 3))
+            set_stall_policy(None)
+            # forward only = BASELINE.json configs[1] as written (QPFunction forward, no backward), on the caller's tensors
+            with torch.no_grad():
+                t_fwd = time_launches(lambda: qpf(tQ.detach(), tp.detach(), tG.detach(), th, tA.detach() if q else tA, tb), nrep)
 
         fwd_r, fwd_w, bwd_r, bwd_w = algorithmic_bytes_per_qp(n, m, q, w)
         ipm_bytes = (fwd_r + fwd_w) * B          # the forward's compulsory traffic, DESIGN.md section 6
@@ -454,6 +505,7 @@ def main():
         achieved = ipm_flops / t_ipm
         peak = MFMA_PEAK[arith]
         traffic, traffic_note = None, "no PMC record for this configuration"
+        other_traffic = {}
         tf = os.path.join(ROOT, "profiles", "ipm_traffic.json")
         if os.path.exists(tf):
             try:
@@ -464,6 +516,7 @@ def main():
                     traffic_note = "PMC record is of another build (%s); re-run scripts/gpu_check.sh" % rec.get("kernel_source_digest")
                 else:
                     traffic, traffic_note = rec.get("hbm_bytes_per_launch"), rec.get("source")
+                    other_traffic = rec.get("other_kernels", {})
             except Exception as e:                      # a broken record is reported, never silently reused
                 traffic_note = "unreadable PMC record: %s" % e
         roofline = {"kernel": "PDIPM loop kernel (k_ipm_tile / k_ipm_grid, one launch per forward)", "bound": "mfma",
@@ -472,6 +525,18 @@ def main():
                     "algorithmic_flops_per_launch": ipm_flops,
                     "algorithmic_bytes_per_launch": ipm_bytes, "hbm_frac": ipm_bytes / t_ipm / HBM_PEAK,
                     "launch_ms": t_ipm * 1e3, "kernel_source_digest": kernel_source_digest()}
+        # the two other launches of a step, both HBM-side: bytes they have to move (SURVEY 8d's backward reads + the one
+        # gradient the benchmark asks for; the pre-factorisation's reads of Q, G, A + the factor blob it exists to write)
+        # against the bytes the counters saw (same PMC passes, same digest rule as `traffic`)
+        pre_bytes = (w * (n * n + m * n + q * n) + fac.elems * fac.blob.element_size()) * B
+        bwd_bytes = (bwd_r + w * n) * B
+        roofline["other_kernels"] = {
+            "pre_factor": {"bound": "hbm", "algorithmic_bytes_per_launch": pre_bytes, "launch_ms": t_pre * 1e3,
+                           "achieved": pre_bytes / t_pre / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": pre_bytes / t_pre / HBM_PEAK,
+                           "traffic": (other_traffic.get("pre_factor") or {}).get("hbm_bytes_per_launch")},
+            "backward": {"bound": "hbm", "algorithmic_bytes_per_launch": bwd_bytes, "launch_ms": t_bwd * 1e3,
+                         "achieved": bwd_bytes / t_bwd / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bwd_bytes / t_bwd / HBM_PEAK,
+                         "traffic": (other_traffic.get("backward") or {}).get("hbm_bytes_per_launch")}}
 
         # Large-QP family (C4): a forward is ~400 stream-ordered launches; the dominant kernel is the MFMA tile GEMM
         # (k_big_gemm, ~70 % of the time).  Its largest launch, R = Zt Zt^T of the pre-factorisation, is re-issued
@@ -500,6 +565,8 @@ def main():
                         "whole_loop": {"what": "all launches of qpx_ipm together, algorithmic flops of the loop / their time",
                                        "achieved": achieved / 1e12, "frac": achieved / peak}}
 
+        wall["kernel_timing"] = time.perf_counter() - w0
+        w0 = time.perf_counter()
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1 and not args.shared:      # reported at N = 1 only
             from oracle import qp_oracle as orc
@@ -534,6 +601,8 @@ def main():
                                       % (Bs, args.dtype, int(info["trips"]), iters_mean, ncpu),
                             "reference_pytorch_cpu": reference_cpu_record(args.dtype)}
 
+        wall["cpu_baseline"] = time.perf_counter() - w0
+        wall["total"] = time.perf_counter() - t_start
         names = {"c2": "C2", "c3": "C3", "c4": "C4", "c5": "C5", "custom": "custom"}
         out = {
             "metric": "QPs/sec (fwd+bwd) at batch=512 nz=100 nineq=100; 1/2/4/8 MI355X",
@@ -555,9 +624,14 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "ms_per_step_median_of_10_step_chunks": float(np.median(chunk_ms)),
-            "fwd_only": {"qps": B / t_fwd, "ms": t_fwd * 1e3, "what": "QPFunction forward under no_grad (BASELINE.json configs[1])"},
+            "first_20_steps_qps": global_B * 20 / first20,
+            "first_20_steps_what": "the protocol of rounds 1-4 in this same process: %d warm-up steps, then 20 timed steps, as the "
+                                   "process' first GPU work, before the untimed spin-up" % args.warmup,
+            "wall_s": {k: round(v, 3) for k, v in wall.items()},
+            "fwd_only": None if t_fwd is None else {"qps": B / t_fwd, "ms": t_fwd * 1e3, "what": "QPFunction forward under no_grad (BASELINE.json configs[1])"},
             "kernel_ms": {"pre_factor": t_pre * 1e3, "ipm": t_ipm * 1e3, "backward": t_bwd * 1e3,
-                          "backward_all_gradients": t_bwd_all * 1e3, "ipm_all_20_iterations": t_ipm_fixed * 1e3},
+                          "backward_all_gradients": None if t_bwd_all is None else t_bwd_all * 1e3,
+                          "ipm_all_20_iterations": None if t_ipm_fixed is None else t_ipm_fixed * 1e3},
             "job_hbm_roofline_frac": value / world * (fwd_r + fwd_w + bwd_r + bwd_w) / HBM_PEAK,
         }
         if extra is not None:

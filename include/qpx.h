@@ -17,9 +17,17 @@
  * Conventions
  *   - dtype: QPX_F32 or QPX_F64: every `void*` array below has that element type; or QPX_F32_WIDE (see the enum).
  *   - All pointers are DEVICE pointers valid on `stream` (a hipStream_t).  The caller owns every
- *     buffer; the library never allocates, frees or synchronises.  Calls are stream-ordered and
+ *     buffer; the library never allocates or frees device memory.  Calls are stream-ordered and
  *     re-entrant: the only mutable state is the A/B knob of qpx_set_ipm_variant, which is per host
  *     thread (thread_local) and which nothing but measurements and tests should touch.
+ *   - No call synchronises with the host, with ONE exception, in the large-QP family only (nz+neq+nineq > 208) when
+ *     a batch of >= 96 QPs is worked on in two parts on two streams (the default there; knob bits 16..19 = 1 turns it
+ *     off): the first call of a host thread on a device creates one side stream (kept for the thread's life) and
+ *     checks ONCE per (side stream, caller stream) pair -- the last 8 pairs are remembered -- that the two really run
+ *     side by side (HIP may deal both to one hardware queue: the parts would serialise, 2 x slower).  That check
+ *     enqueues two 100-us delay kernels and waits for them on the host (~0.3 ms; it also waits for whatever the
+ *     caller had queued on `stream` before).  It is skipped while `stream` is being captured into a graph and when
+ *     the environment variable QPX_NO_STREAM_PROBE is set (then the first side stream is taken as it comes).
  *   - Arrays are dense, row-major, batch-major: Q (B,n,n), p (B,n), G (B,m,n), h (B,m),
  *     A (B,q,n), b (B,q).  A batch stride (in elements) of 0 means "one copy shared by the whole
  *     batch" (the reference's un-batched parameters, qpth/util.py:44-50).  q = 0: A, b unused.
@@ -43,7 +51,7 @@
 extern "C" {
 #endif
 
-#define QPX_ABI_VERSION 7
+#define QPX_ABI_VERSION 8
 
 /* QPX_F32_WIDE (ABI v4): the caller's arrays are float32, `factors` and all arithmetic are float64 -- every `void*`
  * array below except `factors` has float elements, `factors` holds qpx_factor_elems(QPX_F32_WIDE, ...) DOUBLES.  On
@@ -114,8 +122,10 @@ int qpx_refine_supported(int dtype, int n, int m, int q);
  * forms -- a pre-factorisation by a sweep on matrix-core tiles and the four-wave tile kernels without their chain wave
  * -- that lost their A/Bs and were deleted.)
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
- * stream of its own (the caller's + side streams forked from and joined back into it with events, no host
- * synchronisation), 0 = one part; bits 20..24 = initial stagger between the side streams in units of 16 us; (bit 25 selected
+ * stream of its own (the caller's + side streams forked from and joined back into it with events; the one host wait
+ * this can involve is described under "Conventions"), 0 = automatic: two parts from 96 QPs up, else one -- in every
+ * entry point that runs the family's launch sequence (qpx_pre_factor, qpx_ipm / qpx_forward, qpx_factor_solve_kkt,
+ * qpx_backward, qpx_polish); bits 20..24 = initial stagger between the side streams in units of 16 us; (bit 25 selected
  * the four-wave substitutions of round 3 until v7: retired with them); bit 26 = the mat-vec R z' in front of the factorisation
  * in the caller's stream (the round-3 order) instead of beside it on a helper stream; bit 27 =
  * diagonal blocks eliminated by one wave (the round-3 form) instead of four in the chain-wave form; bit 28 = on the
@@ -195,9 +205,10 @@ int qpx_backward(int dtype, int B, int n, int m, int q, void* factors, int64_t s
  * qpx_pre_factor and refined `refine` times on the residual of the original system (kkt_resid_reg / solve_kkt_ir,
  * batch.py:228-270 -- what forward(solver=KKTSolvers.IR_UNOPT) asks for).  The four arrays are overwritten with the BEST
  * iterate met (the reference's rule, batch.py:118-139: residual ||rx|| + ||rz|| + ||ry|| + nineq mu, strict <, NaN never
- * wins; the start iterate competes), best_resid (dtype[B], may be NULL) with its residual.  Served where the
- * thread-grid / tile kernels run (nz+neq+nineq <= 208; dtype QPX_F32 or QPX_F64): qpx_polish_supported; elsewhere
- * QPX_ERR_UNSUPPORTED.  Strides as everywhere: elements, 0 = shared by the batch. */
+ * wins; the start iterate competes), best_resid (dtype[B], may be NULL) with its residual.  Served by every kernel
+ * family since v7 (dtype QPX_F32 or QPX_F64; one kernel up to nz+neq+nineq = 208, the large-QP family's launch sequence
+ * beyond, where `refine` must be 0: qpx_refine_supported); qpx_polish_supported says so; QPX_F32_WIDE and sizes beyond
+ * qpx_max_dim(): QPX_ERR_UNSUPPORTED.  Strides as everywhere: elements, 0 = shared by the batch. */
 int qpx_polish_supported(int dtype, int n, int m, int q);
 int qpx_polish(int dtype, int B, int n, int m, int q,
                const void* Q, int64_t sQ, const void* p, int64_t sp, const void* G, int64_t sG, const void* h, int64_t sh,
@@ -210,7 +221,10 @@ int qpx_polish(int dtype, int B, int n, int m, int q,
  * forms B outer products and then `.mean(0)`): one contraction over the batch instead,
  *   out (r,c) = scale/B * sum_b ( u[b][r] v[b][c] + w[b][r] x[b][c] )        u, w: (B,r)  v, x: (B,c)
  * dQ: u = dx, v = zhat, w = zhat, x = dx, scale = 0.5;  dG: u = dz, v = zhat, w = lam, x = dx, scale = 1;
- * dA: u = dy, v = zhat, w = nu, x = dx.  `out` is (r,c) of dtype, overwritten. */
+ * dA: u = dy, v = zhat, w = nu, x = dx.  `out` is (r,c) of dtype, overwritten.
+ * v8: w == x == NULL: the second product is left out; v == NULL (c must be 1): v is a column of ones, i.e.
+ *   out (r) = scale/B * sum_b u[b][r]  -- the `.mean(0)` of a shared VECTOR parameter's gradient (dp = mean dx,
+ *   dh = -mean dz, db = -mean dy: qp.py:160-166,174-177), in the same fixed order of additions. */
 int qpx_batch_outer(int dtype, int B, int r, int c, const void* u, const void* v, const void* w,
                     const void* x, double scale, void* out, void* ws, size_t ws_elems, qpx_stream_t stream);
 /* v7: `ws` -- ws_elems elements of dtype, at least qpx_batch_outer_workspace_elems(dtype, B, r, c) -- lets a long batch be

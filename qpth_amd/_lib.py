@@ -119,7 +119,7 @@ class QpxLib:
                 continue
             fn = getattr(self.dll, name)       # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if strict and self.dll.qpx_abi_version() != 7:
+        if strict and self.dll.qpx_abi_version() != 8:
             raise RuntimeError("qpth_amd: ABI version mismatch in %s" % path)
 
     def check(self, code):
@@ -188,8 +188,9 @@ class QpxLib:
 
     # -- qp.py:159-177, the `.mean(0)` of a shared parameter's gradient as one contraction over the batch
     def batch_outer(self, u, v, w, x, scale, out):
+        """v is None: the batch mean of u's columns times `scale` (out: (r,)); w, x None: one product only"""
         B, r = u.shape
-        c = v.shape[1]
+        c = v.shape[1] if v is not None else 1
         code = _dtype_code(out)
         # long batches: partial tiles per batch chunk in a workspace, summed in chunk order by a second launch
         need = int(self.dll.qpx_batch_outer_workspace_elems(code, B, r, c))

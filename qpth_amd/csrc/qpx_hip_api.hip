@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/qpx.h"
 #include "qpx_launch.h"
@@ -17,8 +18,11 @@ struct SidePool {
     // [kMaxSide, kPoolSlots): one helper stream per part (R z' beside the factorisation), part i -> kMaxSide + i
     hipStream_t s[kPoolSlots];
     hipEvent_t fork[kPoolSlots], done[kPoolSlots];
-    void* beside[kPoolSlots] = {};        // the caller's stream a slot was last checked against (runs_beside)
-    bool checked[kPoolSlots] = {};
+    // the caller's streams a slot has been checked against (runs_beside), most recent kSeen of them: a caller that
+    // alternates between a few streams is probed once per stream, not at every switch
+    static constexpr int kSeen = 8;
+    void* beside[kPoolSlots][kSeen] = {};
+    int nseen[kPoolSlots] = {};
     bool ok[kPoolSlots] = {};             // created on first use, slot by slot: a process holds the streams it uses (typically
                                           // one: the second part, or the helper), not seven -- streams share the device's four
                                           // hardware queues, and an idle stream that sits on the caller's queue serialises with it
@@ -42,6 +46,14 @@ __global__ void k_stream_delay(long long ticks)
 // device and caller stream); it is skipped while the caller's stream is being captured into a graph.
 static bool runs_beside(hipStream_t caller, hipStream_t side)
 {
+    // the first launch of the delay kernel in a process loads its code object: not inside the timed pair (a cold first
+    // candidate would be rejected for that alone)
+    static thread_local bool warmed = false;
+    if (!warmed) {
+        hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, side, 0LL);
+        (void)hipStreamSynchronize(side);
+        warmed = true;
+    }
     hipEvent_t e0, e1, es;
     if (hipEventCreate(&e0) != hipSuccess) return true;
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return true; }
@@ -71,9 +83,25 @@ static int side_slot(SidePool& p, int i, hipStream_t caller)
             hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) != hipSuccess)
             return QPX_ERR_LAUNCH;
         p.ok[i] = true;
-        p.checked[i] = false;
+        p.nseen[i] = 0;
     }
-    if (capturing || (p.checked[i] && p.beside[i] == (void*)caller)) return QPX_OK;
+    if (capturing) return QPX_OK;
+    for (int k = 0; k < p.nseen[i]; ++k)
+        if (p.beside[i][k] == (void*)caller) return QPX_OK;
+    static const bool no_probe = std::getenv("QPX_NO_STREAM_PROBE") != nullptr;
+    if (no_probe) return QPX_OK;
+    if (p.nseen[i] > 0 && runs_beside(caller, p.s[i])) {
+        // the slot's stream runs beside this stream of the caller too: one more verdict to remember
+        if (p.nseen[i] == SidePool::kSeen) {
+            for (int k = 1; k < SidePool::kSeen; ++k) p.beside[i][k - 1] = p.beside[i][k];
+            p.nseen[i] = SidePool::kSeen - 1;
+        }
+        p.beside[i][p.nseen[i]++] = (void*)caller;
+        return QPX_OK;
+    }
+    // a fresh slot, or one whose stream shares a hardware queue with this caller stream: candidates until one runs beside
+    // it (the verdicts about the replaced stream go with it)
+    p.nseen[i] = 0;
     hipStream_t rejected[3];
     int nrej = 0;
     while (!runs_beside(caller, p.s[i]) && nrej < 3) {
@@ -83,8 +111,7 @@ static int side_slot(SidePool& p, int i, hipStream_t caller)
         p.s[i] = next;
     }
     for (int r = 0; r < nrej; ++r) (void)hipStreamDestroy(rejected[r]);
-    p.checked[i] = true;
-    p.beside[i] = (void*)caller;
+    p.beside[i][p.nseen[i]++] = (void*)caller;
     return QPX_OK;
 }
 

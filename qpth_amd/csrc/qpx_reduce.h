@@ -25,7 +25,7 @@ namespace qpx {
 
 template <class T> struct OuterArgs {
     int B, r, c;
-    const T *u, *v, *w, *x;
+    const T *u, *v, *w, *x;      // v == null: a column of ones (c = 1): the batch mean of u's columns; w == null: no second product
     T scale;          // already divided by B
     T* out;
     T* ws;            // two-stage form: chunks x tiles x 256 partial sums (accumulator layout); else null
@@ -64,6 +64,7 @@ template <class T> QPX_DEV void batch_outer_body(const Block& b, const OuterArgs
     const int b0 = chunk * a.chunk_len, b1 = (b0 + a.chunk_len < a.B) ? b0 + a.chunk_len : a.B;
     // this wave's part of the chunk: multiples of 16 QPs, dealt round-robin (16 QPs = four MFMA pairs per trip)
     T acc[4] = {T(0), T(0), T(0), T(0)};
+    const bool hv = a.v != nullptr, hw = a.w != nullptr;      // (uniform: scalar branches around whole loads)
     for (int bb = b0 + 16 * wv; bb < b1; bb += 16 * nw) {
         T au[4], bv[4], aw[4], bx[4];
 #pragma unroll
@@ -71,9 +72,9 @@ template <class T> QPX_DEV void batch_outer_body(const Block& b, const OuterArgs
             const int bi = bb + 4 * k + g;
             const int bic = bi < b1 ? bi : b1 - 1;
             au[k] = a.u[(size_t)bic * a.r + ric];
-            bv[k] = a.v[(size_t)bic * a.c + cjc];
-            aw[k] = a.w[(size_t)bic * a.r + ric];
-            bx[k] = a.x[(size_t)bic * a.c + cjc];
+            bv[k] = hv ? a.v[(size_t)bic * a.c + cjc] : T(1);
+            aw[k] = hw ? a.w[(size_t)bic * a.r + ric] : T(0);
+            bx[k] = hw ? a.x[(size_t)bic * a.c + cjc] : T(0);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

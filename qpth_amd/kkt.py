@@ -7,6 +7,7 @@ are all shared by the batch (un-batched parameters, qpth/util.py:44-50) the blob
 once and every workgroup reads the same copy.
 """
 import contextlib
+import threading
 
 import numpy as np
 import torch
@@ -46,19 +47,33 @@ def _is_shared(X, B):
     return X.dim() == 2 or X.stride(0) == 0 or (B > 1 and X.size(0) == 1)
 
 
-_PINNED = {}
+class _PinnedPool:
+    """Pinned int32 host buffers for the one small D2H copy behind a pre-factorisation (the per-QP status words).  A buffer
+    belongs to exactly ONE KKTFactors from `take` until that object has read it (raise_on_failure) or dies; only then can
+    another build() get it -- nothing is handed out twice however many builds are outstanding, and two host threads may
+    build at once (autograd runs backward on threads of its own).  Allocating pinned memory per call would cost more than
+    the kernels the asynchronous copy lets the host overlap, hence the free lists."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._free = {}
+
+    def take(self, device, count):
+        key = (device.type, device.index, int(count))
+        with self._lock:
+            lst = self._free.get(key)
+            if lst:
+                return key, lst.pop()
+        return key, torch.zeros(count, dtype=torch.int32).pin_memory()
+
+    def give(self, key, buf, keep=32):
+        with self._lock:
+            lst = self._free.setdefault(key, [])
+            if len(lst) < keep:
+                lst.append(buf)
 
 
-def _pinned_ints(device, count, nring=16):
-    """`count` int32 of pinned host memory from a small ring per (device, count): allocating pinned
-    memory per call would cost more than the kernels it lets us overlap."""
-    key = (device.type, device.index, int(count))
-    ring = _PINNED.get(key)
-    if ring is None:
-        ring = _PINNED[key] = [[torch.zeros(count, dtype=torch.int32).pin_memory() for _ in range(nring)], 0]
-    i = ring[1]
-    ring[1] = (i + 1) % nring
-    return ring[0][i]
+_PINNED = _PinnedPool()
 
 
 class KKTFactors:
@@ -119,14 +134,28 @@ class KKTFactors:
         # status bits that matter are final once the pre-factorisation kernel has run, so the status words are
         # copied to pinned host memory right behind it and read (raise_on_failure) after the loop kernel
         # has been enqueued: the host waits for the pre-factorisation only, never for the IPM loop.
-        self._pre_host = self._pre_event = None
+        self._pre_host = self._pre_event = self._pre_key = self._pre_bits = None
         if self.status.is_cuda:
             # one DMA of the per-QP status words, no reduction kernels in the stream
-            self._pre_host = _pinned_ints(self.device, nblob)
+            self._pre_key, self._pre_host = _PINNED.take(self.device, nblob)
             self._pre_host.copy_(self.status[:nblob], non_blocking=True)
             self._pre_event = torch.cuda.Event()
             self._pre_event.record(torch.cuda.current_stream(self.device))
         return self
+
+    def _release_pinned(self, done):
+        """the pinned buffer goes back to the pool once the copy into it has completed (`done`), else it is dropped"""
+        host, key = self._pre_host, self._pre_key
+        self._pre_host = self._pre_key = None
+        if host is not None and done:
+            _PINNED.give(key, host)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_pre_host", None) is not None:
+                self._release_pinned(self._pre_event.query())
+        except Exception:          # interpreter shutdown: nothing to give back to
+            pass
 
     @contextlib.contextmanager
     def _knob(self):
@@ -146,8 +175,11 @@ class KKTFactors:
     def raise_on_failure(self, check_Q_spd=False):
         mask = _lib.ST_Q_NOT_SPD | _lib.ST_A_RANK
         if self._pre_event is not None:
-            self._pre_event.synchronize()
-            st = int(np.bitwise_or.reduce(self._pre_host.numpy())) & mask
+            if self._pre_bits is None:         # first reading: wait for the copy, keep the bits, free the buffer
+                self._pre_event.synchronize()
+                self._pre_bits = int(np.bitwise_or.reduce(self._pre_host.numpy()))
+                self._release_pinned(True)
+            st = self._pre_bits & mask
         else:
             st = int(np.bitwise_or.reduce(self.status.cpu().numpy().reshape(-1))) & mask
         if st & _lib.ST_Q_NOT_SPD:
@@ -247,6 +279,8 @@ a non-zero diagonal.
             if q:
                 self._check(b, q, "b")
             if not self.refine_ok:
+                # the large-QP family has no refinement inside its KKT solves (qpx_refine_supported): the finishing steps
+                # themselves run, their solves un-refined -- QPFunction(refine=k) never asks for more
                 refine = 0
             for name in ("zhat", "lam", "slacks") + (("nu",) if q else ()):
                 setattr(res, name, getattr(res, name).contiguous())
@@ -254,8 +288,11 @@ a non-zero diagonal.
                 self.lib.polish(B, n, m, q, self.Q, p, self.G, h, self.A if q else None, b if q else None, self.blob, self.sfac,
                                 steps, refine, res.zhat, res.nu if q else None, res.lam, res.slacks, None, self.status)
             return res
-        raise RuntimeError("qpth_amd: no finishing stage for this size / dtype under the current knob (float32 tensors in "
-                           "float64 arithmetic do not need one; see QPFunction.__doc__)")
+        if self.wide:
+            # float32 tensors in float64 arithmetic: the loop's answer already is the float64 solution of the data (DESIGN
+            # 3.4), there is nothing for residuals in float64 to add; rounds 2-4 ran a host-composed stage here
+            return res
+        raise RuntimeError("qpth_amd: no finishing stage for this size / dtype under the current knob")
 
     # -- QPFunctionFn.backward (qp.py:127-182) ------------------------------------------------
     def backward(self, zhat, lam, slacks, nu, dl_dz, want=(True,) * 6, shared=(False,) * 6, refine=0):
@@ -300,10 +337,15 @@ a non-zero diagonal.
             if wA and sA:
                 dA = torch.empty(q, n, dtype=dt, device=dev)
                 self.lib.batch_outer(dy, zh, nv, dx, 1.0, dA)
-        if wp and sp:
-            dp = dx.mean(0)
-        if wh and sh:
-            dh = -dz.mean(0)
-        if wb and sb:
-            db = -dy.mean(0)
+            # shared vectors: the same contraction with a column of ones (ABI v8) -- `.mean(0)` in a fixed order of
+            # additions, the sign of qp.py:160-166 folded into the scale
+            if wp and sp:
+                dp = torch.empty(n, dtype=dt, device=dev)
+                self.lib.batch_outer(dx, None, None, None, 1.0, dp)
+            if wh and sh:
+                dh = torch.empty(m, dtype=dt, device=dev)
+                self.lib.batch_outer(dz, None, None, None, -1.0, dh)
+            if wb and sb:
+                db = torch.empty(q, dtype=dt, device=dev)
+                self.lib.batch_outer(dy, None, None, None, -1.0, db)
         return dQ, dp, dG, dh, dA, db

@@ -144,7 +144,14 @@ def factor_solve_kkt_reg(Q_tilde, D, G, A, rx, rs, rz, ry, eps):
         cols = [fac.solve_kkt(dreg_b, None, None, None, eye[j].expand(nBatch, neq).contiguous())[3] for j in range(neq)]
         Y = torch.stack(cols, dim=2)                                     # Y[:, :, j] = dy for ry = e_j
         # (I + eps Y) dy = dy0: one general neq x neq system per QP, by the library's pivoted elimination kernel
-        dy_reg = fac.lib.dense_solve((eye + eps * Y).contiguous(), dy0.clone().contiguous(), fac.status)
+        st = torch.zeros(nBatch, dtype=torch.int32, device=Q_tilde.device)
+        dy_reg = fac.lib.dense_solve((eye + eps * Y).contiguous(), dy0.clone().contiguous(), st)
+        # the reference's torch.linalg.solve raised on a singular system (batch.py:294-303 is an LU solve that fails);
+        # the kernel reports it per QP and returns NaNs -- read the words (this entry point is off the QPFunction path: the
+        # one small D2H copy and the wait are what torch's own error check costs too) and raise as the reference does
+        if int(st.max().item()) & _dp._lib.ST_KKT_BREAKDOWN:
+            raise RuntimeError("qpth_amd: factor_solve_kkt_reg: the regularised (y, y) block (I + eps Y) is singular for QP(s) %s"
+                               % torch.nonzero(st).flatten().tolist()[:8])
         ry_eff = ry0 - eps * dy_reg
     dx, _, dz, dy = fac.solve_kkt(dreg, rx, rs_reg, rz, ry_eff)
     ds = (-rs_ - dz) / (d if d.dim() == 2 else d.unsqueeze(0))      # the second block row with the caller's d

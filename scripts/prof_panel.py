@@ -26,7 +26,7 @@ NAMES = NAMES16 if PANEL == 16 else NAMES4
 def main():
     B, n, m, q = [int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (512, 100, 100, 0))]
     dev = torch.device("cuda:0")
-    lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_pprof.so"))
+    lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_pprof.so"), strict=False)
     _lib.set_test_backend(lib)
     lib.dll.qpx_set_ipm_variant(int(os.environ.get("QPX_VARIANT", "0")))
     arrs = problems.prof_qp(B, n, m, q, 0, np.float64)

@@ -20,7 +20,7 @@ def main():
     B, n, m, q = [int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (512, 100, 100, 0))]
     dt = np.float32 if (len(sys.argv) > 5 and sys.argv[5] == "f32") else np.float64
     dev = torch.device("cuda:0")
-    lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_prof.so"))
+    lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_prof.so"), strict=False)
     _lib.set_test_backend(lib)        # explicit: route this script's calls to the profiling build
     lib.dll.qpx_set_ipm_variant(int(os.environ.get("QPX_VARIANT", "0")))
     arrs = problems.prof_qp(B, n, m, q, 0, dt)

@@ -21,7 +21,7 @@ NAMES = ["Q -> LDS", "tiles out of LDS", "ldl_inv", "V -> LDS", "K tiles (share)
 def main():
     B, n, m = [int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (512, 100, 100))]
     dev = torch.device("cuda:0")
-    lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_prof.so"))
+    lib = _lib.QpxLib(os.path.join(ROOT, "qpth_amd", "libqpx_hip_prof.so"), strict=False)
     _lib.set_test_backend(lib)
     lib.dll.qpx_set_ipm_variant(int(os.environ.get("QPX_VARIANT", "0")))
     tQ, tp, tG, th, tA, tb = [torch.tensor(x, device=dev) for x in problems.prof_qp(B, n, m, 0, 0)]

@@ -746,9 +746,20 @@ def test_batch_contraction_in_two_stages(shape, dtype):
         one = torch.full((r, c), float("nan"), dtype=dtype)
         lib.check(lib.dll.qpx_batch_outer(code, B, r, c, u.data_ptr(), v.data_ptr(), w.data_ptr(), x.data_ptr(), 0.5,
                                           one.data_ptr(), None, 0, None))                 # no workspace: one stage
-    assert torch.equal(outs[0], outs[1])
+        # ABI v8: v == NULL = a column of ones, w == x == NULL = no second product: the batch mean of u's columns, with
+        # the sign in the scale -- the `.mean(0)` of a shared VECTOR parameter's gradient (qp.py:160-166,174-177)
+        means = []
+        for rep in range(2):
+            mo = torch.full((r,), float("nan"), dtype=dtype)
+            lib.batch_outer(u, None, None, None, -1.0, mo)
+            means.append(mo)
+        bad = lib.dll.qpx_batch_outer(code, B, r, c + 1, u.data_ptr(), None, None, None, 1.0, one.data_ptr(), None, 0, None)
+    assert bad == -1                                                    # QPX_ERR_ARG: a column of ones means c = 1
+    assert torch.equal(outs[0], outs[1]) and torch.equal(means[0], means[1])
     for o in (outs[0], one):
         assert (o.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    mref = -u.double().mean(0)
+    assert (means[0].double() - mref).abs().max().item() <= tol * max(1.0, mref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])

@@ -1,7 +1,13 @@
 """-m gpu: the multi-GPU path over RCCL (backend "nccl") on however many MI355X are visible -- batch shards per
 rank, zhat all_gathered, shared-parameter gradient all_reduced to the global mean.  The same
-code is covered on CPU by tests/test_dist_gloo.py (gloo, world_size 2).  With one visible GPU the test SKIPS (and
-says so): a single-device run proves nothing about RCCL."""
+code is covered on CPU by tests/test_dist_gloo.py (gloo, world_size 2).
+
+With one visible GPU the tests that need a second DEVICE skip (and say so).  The tests named `*_world_size_one` do not:
+RCCL initialises, all_gathers and all_reduces with a single rank too, so the whole `nccl` code path of the package and
+of bench.py -- communicator set-up on the device, all_gather_into_tensor on RCCL's own stream beside the backward
+launches, the scaled all_reduce of a shared parameter's gradient, bench.py's distributed branch with its C5 point --
+executes on the one GPU a box has (round 6: until then the first 8-GPU run would have been that code's first execution
+on any GPU).  They prove the plumbing, not the scaling."""
 import os
 import socket
 
@@ -41,7 +47,12 @@ def _worker(rank, world, port, out_dir):
     tG, th, tA, tb = [torch.tensor(x, device=dev) for x in (G, h, A, b)]
     lo, hi = qdist.shard_bounds(nB, rank, world)
     z_local, z_full = qdist.solve_sharded(QPFunction(verbose=-1), Qs, tp, tG, th, tA, tb, nB)
+    # the collective bench.py overlaps with the backward: all_gather_into_tensor (equal slices) / all_gather (ragged ones)
+    # in flight on RCCL's stream while the backward launches are enqueued, waited for afterwards
+    pending = qdist.gather_batch(z_local.detach(), nB, async_op=True)
     z_local.backward(torch.ones_like(z_local))
+    z_async = pending.wait()
+    assert torch.equal(z_async, z_full)
     dQ = qdist.reduce_shared_grad(Qs.grad, hi - lo, nB)
     dp_full = tp.grad.clone()
     dist.all_reduce(dp_full, op=dist.ReduceOp.SUM)
@@ -55,10 +66,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_rccl_batch_sharding(tmp_path):
-    world = torch.cuda.device_count()
-    if world < 2:
-        pytest.skip("RCCL PATH NOT EXERCISED: %d GPU visible on this box (needs >= 2)" % world)
+def _run_and_compare(world, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     out = np.load(tmp_path / "out.npz")
@@ -81,6 +89,51 @@ def test_rccl_batch_sharding(tmp_path):
     x1, nu1, lam1, s1 = pdipm_b.forward(Qe, tp.detach(), tG, th, tA, tb, Q_LU, S_LU, R, verbose=-1)
     assert rel_err(out["x"], x1.cpu().numpy()).max() < 1e-9 and rel_err(out["nu"], nu1.cpu().numpy()).max() < 1e-9
     assert rel_err(out["lam"], lam1.cpu().numpy()).max() < 1e-9 and np.abs(out["s"] - s1.cpu().numpy()).max() < 1e-9
+
+
+def test_rccl_batch_sharding(tmp_path):
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("RCCL PATH NOT EXERCISED ACROSS DEVICES: %d GPU visible on this box (needs >= 2)" % world)
+    _run_and_compare(world, tmp_path)
+
+
+def test_rccl_path_world_size_one(tmp_path):
+    """init_process_group("nccl", world_size=1) in a spawned process, then everything qpth_amd.dist does over RCCL:
+    solve_sharded (all_gather of zhat), gather_batch(async_op=True) beside the backward, reduce_shared_grad,
+    forward_sharded (zhat, nu, lam, slacks gathered); the result must be the plain single-process one.  Never skips."""
+    _run_and_compare(1, tmp_path)
+
+
+def _bench_line(cmd, env, timeout):
+    import json
+    import subprocess
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_distributed_branch_world_size_one(tmp_path):
+    """bench.py --gpus 1 with QPX_FORCE_DIST=1: the branch the driver's N > 1 runs take (RCCL process group, zhat
+    all_gathered beside the backward inside the timed region, MAX over ranks, the C5 strong-scaling point under `extra`)
+    on the one GPU of this box.  The record is kept under gpurun_out/ when that directory exists."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", QPX_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    d = _bench_line([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                    env, 900)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["global_batch"] == 512 and d["value"] > 0
+    assert "all_gathered over RCCL" in d["config"]["workload"]
+    x = d["extra"]["c5_strong_scaling"]
+    assert x["global_batch"] == 65536 and x["per_gpu_batch"] == 65536 and x["n_gpus"] == 1 and x["value"] > 0
+    out_dir = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "nccl_world1_bench.json"), "w") as f:
+            f.write(json.dumps(d) + "\n")
 
 
 def test_bench_strong_scaling_contract_under_torchrun(tmp_path):
