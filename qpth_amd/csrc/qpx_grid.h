@@ -245,6 +245,7 @@ QPX_DEV void grid_solve_neg(const Block& blk, const GridPos<GS>& g, const T (&E)
 // qpx_tile.h).  MP = padded order, NT = threads per QP, scratch = LDS elements the operations use.
 template <class T, int GS, int NBL> struct GridMat {
     static constexpr int NT = GS * GS, MP = GS * NBL;
+    static constexpr bool kAhead = false;      // (TileMat's chain-wave form: the loop's phases re-ordered around a wave that runs ahead)
     using Pos = GridPos<GS>;
     template <class F> static QPX_DEV void with_role(const Pos& p, F&& f) { f(p); }      // (see TileMat::with_role)
     struct Regs { T e[gtri(NBL)]; };
@@ -776,6 +777,123 @@ QPX_DEV void sweep_body(const Block& blk, const PrefactorArgs<T>& a, int qp, T* 
 QPX_LAYOUT_HD size_t lds_elems_sweep(int nbl) { return (size_t)3 * 16 * nbl + 8 + (size_t)nbl * 256; }
 
 // ------------------------------------------------------------------------------------------
+// The O(m) vector blocks of the PDIPM loop, by ONE wave on LDS-resident vectors (a vector of length m is NS slots of 64
+// lanes); shared by the two orders of a pass in ipm_loop_role.
+// Start point (batch.py:61-87): vX = -T^-1 c -> z, s shifted to >= 1 where their minimum is negative; z' = x
+template <class T, int NS>
+QPX_DEV void ipm_start_point(const Block& b, int lane, int m, int M8, const T* vX, T* vZ, T* vS, T* vA, T* vBZ, T* vBS, T* pSigz, T* pSigs)
+{
+    T x[NS];
+    ld_slots<NS>(b, x, vX, m, T(0));
+    T mnz = Lim<T>::inf(), mns = Lim<T>::inf();
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int i = k * kWave + lane;
+        if (i < m) {
+            mnz = (x[k] < mnz) ? x[k] : mnz;
+            mns = (-x[k] < mns) ? -x[k] : mns;
+        }
+    }
+    mnz = wave_min(b, mnz);
+    mns = wave_min(b, mns);
+    const T sigz = (mnz < T(0)) ? (T(1) - mnz) : T(0);
+    const T sigs = (mns < T(0)) ? (T(1) - mns) : T(0);
+    if (lane == 0) { *pSigz = sigz; *pSigs = sigs; }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int i = k * kWave + lane;
+        if (i < m) {
+            const T zk = x[k] + sigz, sk = -x[k] + sigs;
+            vZ[i] = zk; vS[i] = sk;
+            vA[i] = x[k];
+            vBZ[i] = zk; vBS[i] = sk;
+        } else if (i < M8) {
+            vA[i] = T(0);
+        }
+    }
+}
+// Affine step lengths, centring sigma, the corrector's right-hand side (batch.py:160-171)
+template <class T, int NS>
+QPX_DEV void ipm_affine_step(const Block& b, int lane, int m, T mu, T szdot, const T* vZ, const T* vS, const T* vRZ, const T* vRS,
+                             const T* vD, const T* vX, T* vRSC, T* vRH, T* vDZA, T* vDSA)
+{
+    T z[NS], s[NS], rz[NS], rsv[NS], dd[NS], dza[NS], dsa[NS];
+    ld_slots<NS>(b, z, vZ, m, T(1));
+    ld_slots<NS>(b, s, vS, m, T(1));
+    ld_slots<NS>(b, rz, vRZ, m, T(1));
+    ld_slots<NS>(b, rsv, vRS, m, T(1));
+    ld_slots<NS>(b, dd, vD, m, T(1));
+    ld_slots<NS>(b, dza, vX, m, T(0));
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int i = k * kWave + lane;
+        dsa[k] = (i < m) ? (-s[k] - dza[k] * dd[k]) : T(0);
+    }
+    T al = step_to_boundary_rcp<NS>(b, rz, dza, m);
+    const T al2 = step_to_boundary_rcp<NS>(b, rsv, dsa, m);
+    al = (al2 < al) ? al2 : al;
+    al = (al < T(1)) ? al : T(1);
+    T t3 = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int i = k * kWave + lane;
+        if (i < m) t3 = fma_(s[k] + al * dsa[k], z[k] + al * dza[k], t3);
+    }
+    t3 = wave_sum(b, t3);
+    T sig = t3 / szdot;
+    sig = sig * sig * sig;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int i = k * kWave + lane;
+        if (i < m) {
+            const T rs = (-mu * sig + dsa[k] * dza[k]) * rsv[k];
+            vRSC[i] = rs;
+            vRH[i] = rs * dd[k];
+            vDZA[i] = dza[k];
+            vDSA[i] = dsa[k];
+        }
+    }
+}
+// The combined step with the 0.999 damping, tau, z' (batch.py:173-198)
+template <class T, int NS>
+QPX_DEV void ipm_final_step(const Block& b, int lane, int m, T* vZ, T* vS, const T* vRZ, const T* vRS, const T* vD, const T* vX,
+                            const T* vRSC, const T* vDZA, const T* vDSA, T* vA, T* pTau, T* pAlphaPrev, T sigz)
+{
+    T z[NS], s[NS], rz[NS], rsv[NS], dz[NS], ds[NS];
+    ld_slots<NS>(b, z, vZ, m, T(1));
+    ld_slots<NS>(b, s, vS, m, T(1));
+    ld_slots<NS>(b, rz, vRZ, m, T(1));
+    ld_slots<NS>(b, rsv, vRS, m, T(1));
+    ld_slots<NS>(b, dz, vX, m, T(0));
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int i = k * kWave + lane;
+        const T dsc = (i < m) ? ((-vRSC[i] - dz[k]) * vD[i]) : T(0);
+        dz[k] = (i < m) ? (vDZA[i] + dz[k]) : T(0);
+        ds[k] = (i < m) ? (vDSA[i] + dsc) : T(0);
+    }
+    T al = step_to_boundary_rcp<NS>(b, rz, dz, m);
+    const T al3 = step_to_boundary_rcp<NS>(b, rsv, ds, m);
+    al = (al3 < al) ? al3 : al;
+    al = T(0.999) * al;
+    al = (al < T(1)) ? al : T(1);
+    const T tau = (T(1) - al) * *pTau;
+    const T tsz = tau * sigz;
+    b.wave_sync();           // every lane has read the old tau
+    if (lane == 0) { *pTau = tau; *pAlphaPrev = al; }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int i = k * kWave + lane;
+        if (i < m) {
+            const T zk = fma_(al, dz[k], z[k]);
+            vZ[i] = zk;
+            vS[i] = fma_(al, ds[k], s[k]);
+            vA[i] = zk - tsz;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The PDIPM loop on the format-3 blob.  Mathematics and control flow: see ipm_body (same
 // reference citations); the factorisation is ldl_inv and every solve is two triangular mat-vecs.
 template <class T, class Mat, int NS, class P>
@@ -885,6 +1003,138 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
     // vector work, was measured twice: no gain in round 2 -- profiles/archive/r02b_panel_ab.txt, "late" -- and +3 % loop time
     // with the chain-wave form, profiles/archive/r03h_ab_loop_variants.txt.)
     int stop = 0;
+    if constexpr (Mat::kAhead) {
+    // ---- (r6) the same passes with the chain wave AHEAD of the tile waves (TileMat::kAhead): d = s/z of a pass is final when
+    // the previous pass ends, so the chain wave eliminates pivot block 0 while the tile waves load R and form R z', and the
+    // residual / best-iterate / stop bookkeeping runs on it in panel 0's second interval, beside the tile waves' longest
+    // stretch of updates.  The stop decision is read by every wave behind that panel's last barrier; the panel the waves
+    // ran ahead of it on a pass that stops is dropped (T lives in registers nobody reads again).  Mathematics, order of
+    // the floating-point operations and results: those of the order below.
+    typename Mat::Ahead ah;
+    Mat::ahead_init(b, g, ah, Rg);
+    for (int it = -1; it < a.maxIter && !stop; ++it) {
+        const bool first = it < 0;
+        Mat::load(b, g, E, Rg);
+        QPX_PROF(2)
+        if (w0) {
+            if (!first) {
+                // 1/z, 1/s, d = s/z and mu of the iterate the previous pass left (every later division by z or s is a multiplication)
+                T szdot = 0;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int i = k * kWave + lane;
+                    if (i < m) {
+                        const T zk = vZ[i], sk = vS[i];
+                        szdot = fma_(sk, zk, szdot);
+                        const T rzk = rcp_(zk);
+                        vRZ[i] = rzk;
+                        vRS[i] = rcp_(sk);
+                        vD[i] = sk * rzk;
+                    }
+                }
+                szdot = wave_sum(b, szdot);
+                if (lane == 0) { sc[kMu] = abs_(szdot / mT); sc[kSzdot] = szdot; }
+                b.wave_sync();
+            }
+            Mat::ahead_pivot0(b, g, ah, vD, scr, rd, m);
+        }
+        QPX_PROF(4)
+        Mat::template symv<true>(b, g, E, vA, first ? vR1 : vB, scr);       // (its barrier; then the chain wave gathers)
+        QPX_PROF(3)
+        Mat::ahead_publish0(b, g, E, vD, scr);
+        Mat::sync(b);
+        QPX_PROF(2)                  // (profiling build, chain wave: its wait for the tile waves' T = R + D and old rows)
+        const int rc = Mat::ldl_inv_ahead(b, g, E, scr, rd, m, [&] {
+            if (first) return;
+            const T tsz = sc[kTau] * sc[kSigz];
+            T pri2 = 0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) {
+                    const T rz = vS[i] - vC[i] - vB[i];
+                    pri2 = fma_(rz, rz, pri2);
+                }
+            }
+            pri2 = wave_sum(b, pri2);
+            const T mu = sc[kMu];
+            const T pri = sqrt_(pri2);
+            const T dual = tsz * sc[kGt1];         // || G^T 1 ||
+            const T feas = pri + dual, resid = feas + mT * mu;
+            // best iterate and the stop decision (batch.py:118-143)
+            const T tau = sc[kTau];
+            T bres = sc[kBres];
+            int nnot = ctrl[kNnot], floor_hit = ctrl[kFloor];
+            int stopf = 0;
+            const bool better = (it == 0) || (resid < bres);
+            if (better) {
+                bres = resid; nnot = 0;
+                for (int i = lane; i < m; i += kWave) { vBZ[i] = vZ[i]; vBS[i] = vS[i]; }
+            } else if (a.stall_policy == 1 || (a.stall_policy == 2 && mT * mu < feas)) {
+                nnot += 1;
+            } else {
+                nnot = 0;
+            }
+            if (a.stall_policy == 2 && it >= 1 && feas > T(2) * (T(1) - sc[kAlphaPrev]) * sc[kFeasPrev]) floor_hit = 1;
+            if ((a.stall_policy != 0 && nnot >= a.notImprovedLim) || bres < a.eps || mu > T(1e32)) stopf = 1;
+            if (a.stall_policy == 2 && floor_hit && mT * mu < T(1e-2) * feas) stopf = 1;
+            const bool bad = !finite_(resid);
+            if (bad) stopf = 1;
+            b.wave_sync();           // every lane has read the scalars lane 0 is about to replace
+            if (lane == 0) {
+                ctrl[kIters] = it + 1;
+                if (better) { sc[kBres] = bres; sc[kBtau] = tau; }
+                sc[kFeasPrev] = feas;
+                ctrl[kNnot] = nnot; ctrl[kFloor] = floor_hit;
+                if (bad) ctrl[kSt] |= QPX_ST_NONFINITE;
+                ctrl[kStop] = stopf;
+                if (a.trace) {
+                    const size_t tr = ((size_t)it * a.B + qp) * 3;
+                    put_(a.trace, io32, tr, pri); put_(a.trace, io32, tr + 1, dual); put_(a.trace, io32, tr + 2, mu);
+                }
+            }
+        }, [&] {
+            if (first) return;
+            const T tsz = sc[kTau] * sc[kSigz];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * kWave + lane;
+                if (i < m) vRH[i] = vC[i] + vB[i] + tsz * vR1[i];       // affine right-hand side c + R z
+            }
+        }, [&] { return first ? 0 : ctrl[kStop]; });
+        QPX_PROF(5)
+        if (rc < 0) { stop = 1; break; }
+        if (rc > 0) {                // uniform: every wave reads the same flag
+            if (w0) {
+                if (lane == 0) ctrl[kSt] |= QPX_ST_KKT_BREAKDOWN;
+                if (first) {
+                    for (int i = lane; i < M8; i += kWave) {
+                        if (i < m) { vBZ[i] = T(1); vBS[i] = T(1); }
+                        vA[i] = T(0);
+                    }
+                }
+            }
+            break;
+        }
+        QPX_PROF(1)
+        Mat::template solve_neg<true>(b, g, E, rd, m, first ? vC : vRH, vX, vTm, scr);
+        QPX_PROF(6)
+        if (first) {
+            if (w0) ipm_start_point<T, NS>(b, lane, m, M8, vX, vZ, vS, vA, vBZ, vBS, sc + kSigz, sc + kSigs);
+            Mat::sync(b);
+            QPX_PROF(1)
+            continue;
+        }
+        if (w0) ipm_affine_step<T, NS>(b, lane, m, sc[kMu], sc[kSzdot], vZ, vS, vRZ, vRS, vD, vX, vRSC, vRH, vDZA, vDSA);
+        Mat::sync(b);
+        QPX_PROF(1)
+        Mat::template solve_neg<true>(b, g, E, rd, m, vRH, vX, vTm, scr);
+        QPX_PROF(6)
+        if (w0) ipm_final_step<T, NS>(b, lane, m, vZ, vS, vRZ, vRS, vD, vX, vRSC, vDZA, vDSA, vA, sc + kTau, sc + kAlphaPrev, sc[kSigz]);
+        Mat::sync(b);
+        QPX_PROF(1)
+    }
+    } else {
     for (int it = -1; it < a.maxIter && !stop; ++it) {
         const bool first = it < 0;
         Mat::load(b, g, E, Rg);
@@ -975,119 +1225,20 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         Mat::template solve_neg<true>(b, g, E, rd, m, first ? vC : vRH, vX, vTm, scr);
         QPX_PROF(6)
         if (first) {
-            if (w0) {
-                T x[NS];
-                ld_slots<NS>(b, x, vX, m, T(0));
-                T mnz = Lim<T>::inf(), mns = Lim<T>::inf();
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const int i = k * kWave + lane;
-                    if (i < m) {
-                        mnz = (x[k] < mnz) ? x[k] : mnz;
-                        mns = (-x[k] < mns) ? -x[k] : mns;
-                    }
-                }
-                mnz = wave_min(b, mnz);
-                mns = wave_min(b, mns);
-                const T sigz = (mnz < T(0)) ? (T(1) - mnz) : T(0);
-                const T sigs = (mns < T(0)) ? (T(1) - mns) : T(0);
-                if (lane == 0) { sc[kSigz] = sigz; sc[kSigs] = sigs; }
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const int i = k * kWave + lane;
-                    if (i < m) {
-                        const T zk = x[k] + sigz, sk = -x[k] + sigs;
-                        vZ[i] = zk; vS[i] = sk;
-                        vA[i] = x[k];
-                        vBZ[i] = zk; vBS[i] = sk;
-                    } else if (i < M8) {
-                        vA[i] = T(0);
-                    }
-                }
-            }
+            if (w0) ipm_start_point<T, NS>(b, lane, m, M8, vX, vZ, vS, vA, vBZ, vBS, sc + kSigz, sc + kSigs);
             Mat::sync(b);
             QPX_PROF(1)
             continue;
         }
-        if (w0) {
-            const T mu = sc[kMu], szdot = sc[kSzdot];
-            T z[NS], s[NS], rz[NS], rsv[NS], dd[NS], dza[NS], dsa[NS];
-            ld_slots<NS>(b, z, vZ, m, T(1));
-            ld_slots<NS>(b, s, vS, m, T(1));
-            ld_slots<NS>(b, rz, vRZ, m, T(1));
-            ld_slots<NS>(b, rsv, vRS, m, T(1));
-            ld_slots<NS>(b, dd, vD, m, T(1));
-            ld_slots<NS>(b, dza, vX, m, T(0));
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                dsa[k] = (i < m) ? (-s[k] - dza[k] * dd[k]) : T(0);
-            }
-            T al = step_to_boundary_rcp<NS>(b, rz, dza, m);
-            const T al2 = step_to_boundary_rcp<NS>(b, rsv, dsa, m);
-            al = (al2 < al) ? al2 : al;
-            al = (al < T(1)) ? al : T(1);
-            T t3 = 0;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                if (i < m) t3 = fma_(s[k] + al * dsa[k], z[k] + al * dza[k], t3);
-            }
-            t3 = wave_sum(b, t3);
-            T sig = t3 / szdot;
-            sig = sig * sig * sig;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                if (i < m) {
-                    const T rs = (-mu * sig + dsa[k] * dza[k]) * rsv[k];
-                    vRSC[i] = rs;
-                    vRH[i] = rs * dd[k];
-                    vDZA[i] = dza[k];
-                    vDSA[i] = dsa[k];
-                }
-            }
-        }
+        if (w0) ipm_affine_step<T, NS>(b, lane, m, sc[kMu], sc[kSzdot], vZ, vS, vRZ, vRS, vD, vX, vRSC, vRH, vDZA, vDSA);
         Mat::sync(b);
         QPX_PROF(1)
         Mat::template solve_neg<true>(b, g, E, rd, m, vRH, vX, vTm, scr);
         QPX_PROF(6)
-        if (w0) {
-            T z[NS], s[NS], rz[NS], rsv[NS], dz[NS], ds[NS];
-            ld_slots<NS>(b, z, vZ, m, T(1));
-            ld_slots<NS>(b, s, vS, m, T(1));
-            ld_slots<NS>(b, rz, vRZ, m, T(1));
-            ld_slots<NS>(b, rsv, vRS, m, T(1));
-            ld_slots<NS>(b, dz, vX, m, T(0));
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                const T dsc = (i < m) ? ((-vRSC[i] - dz[k]) * vD[i]) : T(0);
-                dz[k] = (i < m) ? (vDZA[i] + dz[k]) : T(0);
-                ds[k] = (i < m) ? (vDSA[i] + dsc) : T(0);
-            }
-            T al = step_to_boundary_rcp<NS>(b, rz, dz, m);
-            const T al3 = step_to_boundary_rcp<NS>(b, rsv, ds, m);
-            al = (al3 < al) ? al3 : al;
-            al = T(0.999) * al;
-            al = (al < T(1)) ? al : T(1);
-            const T tau = (T(1) - al) * sc[kTau];
-            const T tsz = tau * sc[kSigz];
-            b.wave_sync();           // every lane has read the old tau
-            if (lane == 0) { sc[kTau] = tau; sc[kAlphaPrev] = al; }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int i = k * kWave + lane;
-                if (i < m) {
-                    const T zk = fma_(al, dz[k], z[k]);
-                    vZ[i] = zk;
-                    vS[i] = fma_(al, ds[k], s[k]);
-                    vA[i] = zk - tsz;
-                }
-            }
-        }
+        if (w0) ipm_final_step<T, NS>(b, lane, m, vZ, vS, vRZ, vRS, vD, vX, vRSC, vDZA, vDSA, vA, sc + kTau, sc + kAlphaPrev, sc[kSigz]);
         Mat::sync(b);
         QPX_PROF(1)
+    }
     }
 
     // ---- outputs (batch.py:143,207)

@@ -194,6 +194,21 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         }
     }
     struct Regs { T e[NSLOT][4]; };
+    // (r6) Chain-wave form of the LOOP kernel: the chain wave runs ahead of the tile waves across the loop's phases too.
+    // d = s/z of a pass is final when the previous pass ends, and T(0,0) = R(0,0) + diag(d) is R's tile (constant, kept in
+    // the chain wave's registers: it owns no tiles) plus d on the diagonal.  So while the tile waves load R and form R z', the chain wave eliminates pivot block 0; the residual /
+    // best-iterate / stop bookkeeping of the pass (which needs R z') runs on it in the second interval of panels 0 and 1,
+    // where the tile waves' nine-tile updates are the longer side and the chain wave used to wait at the barrier.  Until
+    // round 5 these ran one after the other: mat-vec | vector work | pivot block 0 (three tile waves waiting through the
+    // last two).  The chain wave is the critical resource of a pass: what counts is that nothing is ADDED to its serial
+    // work where it is the longer side (a first version that also moved its share of panel 0's first interval in front of
+    // the mat-vec's barrier made that phase chain-bound: 6.2 k cycles against the tile waves' 4.5 k, and bought 2 % instead
+    // of 8: profiles/r06c_phases.txt).  QPX_NO_AHEAD restores the round-5 order (A/B).
+#ifdef QPX_NO_AHEAD
+    static constexpr bool kAhead = false;
+#else
+    static constexpr bool kAhead = CH;
+#endif
 #ifndef QPX_PIVOT_HEAD
 #define QPX_PIVOT_HEAD 2
 #endif
@@ -462,6 +477,45 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         pivot_load(blk, p, scr, st);
         pivot_run<0, 16>(blk, p, st, kmax);
         pivot_store(blk, p, scr, rd, k0, kmax, sign, st);
+    }
+
+    // ---- the chain wave ahead of the tile waves across the loop's phases (kAhead; see there)
+    struct Ahead {
+        T a00[4], d00;       // R(0,0) in the pivot layout (lane (g, c): row c, columns 4 g .. 4 g + 3) and its diagonal entry
+    };
+    template <class P> static QPX_DEV void ahead_init(const Block&, const P& p0, Ahead& ah, const T* img)
+    {
+        if constexpr (role_of<P>::value == -1) {
+            const P p = p0.fresh();
+            // element (i, j) of tile t sits at img[256 t + (i >> 2) 64 + 16 (i & 3) + j]; diagonal tiles hold both triangles
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ah.a00[j] = img[p.g * 64 + 16 * j + p.c];                          // (4 g + j, c) = (c, 4 g + j)
+            ah.d00 = img[(p.c >> 2) * 64 + 16 * (p.c & 3) + p.c];
+        }
+    }
+    // chain wave, while the tile waves load R and form R z': pivot block 0 of T = R + diag(vd) -> W, rd[0..15], flag
+    template <class P> static QPX_DEV void ahead_pivot0(const Block& blk, const P& p0, const Ahead& ah, const T* vd, T* scr, T* rd, int m)
+    {
+        if constexpr (role_of<P>::value == -1) {
+            const Pos p = p0.fresh();
+            PivotState st;
+            const T dc = vd[p.c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st.a[j] = ah.a00[j] + ((4 * p.g + j == p.c) ? dc : T(0));
+            st.dg = ah.d00 + dc;
+            st.myr = T(1);
+            st.vn = blk.template grp_bcast<0>(st.a[0]);
+            pivot_run<0, 16>(blk, p, st, m);
+            pivot_store(blk, p, scr, rd, 0, m, 1, st);
+        }
+    }
+    // tile waves, after the mat-vec: T = R + diag(vd), and the sixteen old rows of panel 0 -> X
+    template <class P> static QPX_DEV void ahead_publish0(const Block&, const P& p0, Regs& E, const T* vd, T* scr)
+    {
+        if constexpr (role_of<P>::value >= 0) {
+            add_diag(p0, E, vd);
+            publish_rows<role_of<P>::value>(p0.fresh(), E, scr, 0, false);
+        }
     }
 
     // The panel's sixteen old rows -> X (and, with_s, the pivot block itself -> S), from the tiles this wave owns.
@@ -892,6 +946,17 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     template <int ROLE, bool kSweep, class PanelInfo>
     static QPX_DEV int factor_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, int mrows, PanelInfo&& panel)
     {
+        return factor_role_impl<ROLE, kSweep, false>(blk, p0, E, scr, rd, npan, mrows, panel, [] {}, [] {}, [] { return 0; });
+    }
+    // kA (the loop kernel, kAhead): pivot block 0 is done (ahead_pivot0), X and S2 hold panel 0's old rows and E(1, 1)
+    // (ahead_publish0) and a barrier lies behind both.  The chain wave runs `extra1` (the loop's residual / best-iterate /
+    // stop bookkeeping) behind pivot block 1 in panel 0's second interval and `extra2` (the affine right-hand side) in
+    // panel 1's; behind panel 0's barrier X every wave asks `stopped()` and the flag of pivot block 0: -1 = the loop stops
+    // (the panel of speculative work is dropped), > 0 = pivot block 0 broke down.
+    template <int ROLE, bool kSweep, bool kA, class PanelInfo, class Extra1, class Extra2, class Stopped>
+    static QPX_DEV int factor_role_impl(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, int mrows, PanelInfo&& panel,
+                                        Extra1&& extra1, Extra2&& extra2, Stopped&& stopped)
+    {
         constexpr bool kChain = ROLE < 0;
         constexpr int W = kChain ? 0 : ROLE;
         QPX_LAUNDER_S(npan);
@@ -903,10 +968,12 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         T* S2 = scr + kS2;
         T* flag = scr + kFlag;
         // -- panel 0: its rows and pivot block -> X, S (and E(1, 1) -> S2); then the pivot block
-        if constexpr (!kChain) publish_rows<W>(p, E, scr, 0, true);
-        blk.sync();
-        if constexpr (kChain) pivot_block(blk, p, scr, rd, 0, panel(0).kmax, panel(0).sign);
-        blk.sync();
+        if constexpr (!kA) {
+            if constexpr (!kChain) publish_rows<W>(p, E, scr, 0, true);
+            blk.sync();
+            if constexpr (kChain) pivot_block(blk, p, scr, rd, 0, panel(0).kmax, panel(0).sign);
+            blk.sync();
+        }
         long long cacc[5] = {0, 0, 0, 0, 0};
 #ifdef QPX_PANEL_PROF
         cacc[4] = clock64();
@@ -915,7 +982,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #pragma unroll 1
         for (int k = 0; k < npan; ++k) {
             const T zr = flag[0];             // 0 unless a pivot broke down
-            if (zr != T(0)) return (int)zr;
+            if (!(kA && k == 0) && zr != T(0)) return (int)zr;      // (kA: pivot block 0's flag is looked at behind barrier X, after `extra1`)
             const bool la = k + 1 < npan;     // there is a next pivot block
             p = p0.fresh();
             // ---- interval 1: operand tiles; the chain wave brings the next pivot block up to date
@@ -986,6 +1053,10 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                     pivot_run<kPivotHead, 16>(blk, p, pst, panel(k + 1).kmax);
                     pivot_store(blk, p, scr, rd, 16 * (k + 1), panel(k + 1).kmax, panel(k + 1).sign, pst);
                 }
+                if constexpr (kA) {
+                    if (k == 0) extra1();
+                    if (k == 1 || (k == 0 && npan < 2)) extra2();
+                }
             } else {
                 blk.template prio<0>();
                 T nrd[4];
@@ -998,6 +1069,10 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             QPX_CP(2)
             blk.sync();
             QPX_CP(3)
+            if (kA && k == 0) {
+                if (stopped()) return -1;
+                if (zr != T(0)) return (int)zr;
+            }
         }
 #ifdef QPX_PANEL_PROF
         if (p0.lane == 0) {
@@ -1022,6 +1097,17 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     {
         const int npan = (m + 15) / 16 < NBL ? (m + 15) / 16 : NBL;
         return factor_role<ROLE, false>(blk, p0, E, scr, rd, npan, m, [m](int k) { return PanelOf{m - 16 * k, 1}; }) == 0;
+    }
+
+    // the loop kernel's factorisation with the chain wave ahead (kAhead): 0 = done, -1 = the loop stops, > 0 = breakdown
+    template <class P, class Extra1, class Extra2, class Stopped>
+    static QPX_DEV int ldl_inv_ahead(const Block& blk, const P& p, Regs& E, T* scr, T* rd, int m, Extra1&& extra1, Extra2&& extra2, Stopped&& stopped)
+    {
+        static_assert(CH && role_of<P>::value >= -1, "chain-wave form: call through with_role");
+        blk.template prio<3>();
+        const int npan = (m + 15) / 16 < NBL ? (m + 15) / 16 : NBL;
+        return factor_role_impl<role_of<P>::value, false, true>(blk, p, E, scr, rd, npan, m, [m](int k) { return PanelOf{m - 16 * k, 1}; },
+                                                               extra1, extra2, stopped);
     }
 
     // E: T (SPD, order m, padded with the identity) -> strictly lower: W~ = L~^-1, rd[k] = 1/d_k; false: a pivot

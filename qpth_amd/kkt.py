@@ -57,17 +57,44 @@ class _PinnedPool:
     def __init__(self):
         self._lock = threading.Lock()
         self._free = {}
+        self._pending = []          # (event, key, buffer): given up by their owner while the copy was still in flight
 
-    def take(self, device, count):
+    @staticmethod
+    def _done(ev):
+        """True / False: the event has / has not completed; None: it cannot be asked (recorded inside a stream capture):
+        the buffer behind it is dropped rather than handed out"""
+        try:
+            return bool(ev.query())
+        except Exception:
+            return None
+
+    def take(self, device, count, may_allocate=True):
         key = (device.type, device.index, int(count))
         with self._lock:
+            if self._pending:
+                still = []
+                for ev, k, buf in self._pending:
+                    done = self._done(ev)
+                    if done:
+                        self._free.setdefault(k, []).append(buf)
+                    elif done is not None:
+                        still.append((ev, k, buf))
+                self._pending = still
             lst = self._free.get(key)
             if lst:
                 return key, lst.pop()
+        if not may_allocate:
+            return key, None
         return key, torch.zeros(count, dtype=torch.int32).pin_memory()
 
-    def give(self, key, buf, keep=32):
+    def give(self, key, buf, event=None, keep=32):
+        """event: the copy into `buf` may still be in flight -- the buffer is free once the event has completed"""
         with self._lock:
+            done = True if event is None else self._done(event)
+            if not done:
+                if done is not None and len(self._pending) < keep:
+                    self._pending.append((event, key, buf))
+                return
             lst = self._free.setdefault(key, [])
             if len(lst) < keep:
                 lst.append(buf)
@@ -136,24 +163,28 @@ class KKTFactors:
         # has been enqueued: the host waits for the pre-factorisation only, never for the IPM loop.
         self._pre_host = self._pre_event = self._pre_key = self._pre_bits = None
         if self.status.is_cuda:
-            # one DMA of the per-QP status words, no reduction kernels in the stream
-            self._pre_key, self._pre_host = _PINNED.take(self.device, nblob)
-            self._pre_host.copy_(self.status[:nblob], non_blocking=True)
-            self._pre_event = torch.cuda.Event()
-            self._pre_event.record(torch.cuda.current_stream(self.device))
+            # one DMA of the per-QP status words, no reduction kernels in the stream.  (While the stream is being captured
+            # into a graph the pool is left alone -- allocating pinned memory or asking an event would invalidate the
+            # capture: the words stay on the device and raise_on_failure reads them from there.)
+            if not torch.cuda.is_current_stream_capturing():
+                self._pre_key, self._pre_host = _PINNED.take(self.device, nblob)
+            if self._pre_host is not None:
+                self._pre_host.copy_(self.status[:nblob], non_blocking=True)
+                self._pre_event = torch.cuda.Event()
+                self._pre_event.record(torch.cuda.current_stream(self.device))
         return self
 
     def _release_pinned(self, done):
-        """the pinned buffer goes back to the pool once the copy into it has completed (`done`), else it is dropped"""
+        """the pinned buffer goes back to the pool: at once when the copy into it has completed (`done`), else behind its event"""
         host, key = self._pre_host, self._pre_key
         self._pre_host = self._pre_key = None
-        if host is not None and done:
-            _PINNED.give(key, host)
+        if host is not None:
+            _PINNED.give(key, host, None if done else self._pre_event)
 
     def __del__(self):
         try:
             if getattr(self, "_pre_host", None) is not None:
-                self._release_pinned(self._pre_event.query())
+                self._release_pinned(False)
         except Exception:          # interpreter shutdown: nothing to give back to
             pass
 
