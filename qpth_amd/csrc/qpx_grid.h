@@ -1039,12 +1039,10 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
             Mat::ahead_pivot0(b, g, ah, vD, scr, rd, m);
         }
         QPX_PROF(4)
-        Mat::template symv<true>(b, g, E, vA, first ? vR1 : vB, scr);       // (its barrier; then the chain wave gathers)
-        QPX_PROF(3)
-        Mat::ahead_publish0(b, g, E, vD, scr);
+        Mat::ahead_front(b, g, E, vA, vZ, vS, scr);      // tile waves: partial sums of R z' (first pass: R 1), T = R + diag(s/z), panel 0's old rows
         Mat::sync(b);
-        QPX_PROF(2)                  // (profiling build, chain wave: its wait for the tile waves' T = R + D and old rows)
-        const int rc = Mat::ldl_inv_ahead(b, g, E, scr, rd, m, [&] {
+        QPX_PROF(3)                  // (profiling build, chain wave: its wait for the tile waves)
+        const int rc = Mat::ldl_inv_ahead(b, g, E, scr, rd, m, [&] { Mat::ahead_gather(b, lane, scr, first ? vR1 : vB); }, [&] {
             if (first) return;
             const T tsz = sc[kTau] * sc[kSigz];
             T pri2 = 0;

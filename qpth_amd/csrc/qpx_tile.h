@@ -269,9 +269,9 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // Sums over the 16 columns of every tile row of this wave: acc[pp][r] of lane (g, c) is a partial of
     // matrix row 16 I_pp + g + 4 r.  Through LDS: one padded line of 17 per row, one lane adds a line.
     template <class P, class F>
-    static QPX_DEV void row_reduce(const Block& blk, const P& p, const T (&acc)[NPOS][4], T* scr, F&& emit)
+    static QPX_DEV void row_reduce(const Block& blk, const P& p, const T (&acc)[NPOS][4], T* scr, F&& emit, int red_off = kRed)
     {
-        T* red = scr + kRed + p.wi() * (NROW * 17);
+        T* red = scr + red_off + p.wi() * (NROW * 17);
 #pragma unroll
         for (int pp = 0; pp < NPOS; ++pp)
 #pragma unroll
@@ -509,13 +509,68 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             pivot_store(blk, p, scr, rd, 0, m, 1, st);
         }
     }
-    // tile waves, after the mat-vec: T = R + diag(vd), and the sixteen old rows of panel 0 -> X
-    template <class P> static QPX_DEV void ahead_publish0(const Block&, const P& p0, Regs& E, const T* vd, T* scr)
+    // tile waves, in front of the factorisation's first barrier: the partial sums of R vin (symv's, but with the column
+    // partials BEHIND the row-sum scratch: the chain wave adds them up in the factorisation's first interval, while the
+    // tile waves already write the operand tiles BT -- which share LDS with the usual place of the partials); then
+    // T = R + diag(s/z) -- d from z and s themselves, the very operations that give vD its values: nothing of this
+    // depends on the chain wave, so no barrier separates it from the mat-vec -- and the sixteen old rows of panel 0 -> X
+    static constexpr int kPartA = kPart + NWM * NROW * 17;
+    static_assert(!CH || (kPartA >= kBT + NBL * 256 && kPartA + NWM * NBL * 64 <= kRow), "kAhead: the column partials must survive the first operand tiles");
+    template <class P> static QPX_DEV void ahead_front(const Block& blk, const P& p0, Regs& E, const T* vin, const T* vz, const T* vs, T* scr)
     {
         if constexpr (role_of<P>::value >= 0) {
-            add_diag(p0, E, vd);
+            const P p = p0.fresh();
+            T* part = scr + kPartA;
+            T* yrow = scr + kRow;
+            T acc[NPOS][4], u[NPOS][4];
+#pragma unroll
+            for (int pp = 0; pp < NPOS; ++pp) {
+                const int I = p.row(pp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[pp][r] = T(0);
+                    u[pp][r] = I >= 0 ? vin[16 * I + p.g + 4 * r] : T(0);
+                }
+            }
+#pragma unroll
+            for (int J = 0; J < NBL; ++J) {
+                const T xj = vin[16 * J + p.c];
+                T col = 0;
+#pragma unroll
+                for (int pp = 0; pp < NPOS; ++pp) {
+                    if (J >= psize(pp)) continue;
+                    const int I = p.row(pp);
+                    if (J > I) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[pp][r] = fma_(E.e[slot(pp, J)][r], xj, acc[pp][r]);
+                    if (J < I) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) col = fma_(E.e[slot(pp, J)][r], u[pp][r], col);
+                    }
+                }
+                part[(size_t)(p.wi() * NBL + J) * 64 + p.lane] = col;
+            }
+            row_reduce(blk, p, acc, scr, [&](int i, T s) { yrow[i] = s; }, kPart);
+            // T = R + diag(s / z)
+#pragma unroll
+            for (int pp = 0; pp < NPOS; ++pp) {
+                const int I = p.row(pp);
+#pragma unroll
+                for (int J = 0; J < psize(pp); ++J) {
+                    if (J != I) continue;
+                    const T d = vs[16 * J + p.c] * rcp_(vz[16 * J + p.c]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (p.c == p.g + 4 * r) E.e[slot(pp, J)][r] += d;
+                }
+            }
             publish_rows<role_of<P>::value>(p0.fresh(), E, scr, 0, false);
         }
+    }
+    // chain wave, behind that barrier: vout = R vin from the partials
+    static QPX_DEV void ahead_gather(const Block& blk, int lane, const T* scr, T* vout)
+    {
+        gather_cols_wave<false>(blk, lane, scr + kPartA, scr + kRow, vout);
     }
 
     // The panel's sixteen old rows -> X (and, with_s, the pivot block itself -> S), from the tiles this wave owns.
@@ -946,16 +1001,16 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     template <int ROLE, bool kSweep, class PanelInfo>
     static QPX_DEV int factor_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, int mrows, PanelInfo&& panel)
     {
-        return factor_role_impl<ROLE, kSweep, false>(blk, p0, E, scr, rd, npan, mrows, panel, [] {}, [] {}, [] { return 0; });
+        return factor_role_impl<ROLE, kSweep, false>(blk, p0, E, scr, rd, npan, mrows, panel, [] {}, [] {}, [] {}, [] { return 0; });
     }
     // kA (the loop kernel, kAhead): pivot block 0 is done (ahead_pivot0), X and S2 hold panel 0's old rows and E(1, 1)
-    // (ahead_publish0) and a barrier lies behind both.  The chain wave runs `extra1` (the loop's residual / best-iterate /
-    // stop bookkeeping) behind pivot block 1 in panel 0's second interval and `extra2` (the affine right-hand side) in
-    // panel 1's; behind panel 0's barrier X every wave asks `stopped()` and the flag of pivot block 0: -1 = the loop stops
+    // (ahead_front) and a barrier lies behind both.  The chain wave runs `extra0` (it adds up the mat-vec's partial sums) at
+    // the top of panel 0's first interval, `extra1` (the loop's residual / best-iterate / stop bookkeeping) behind pivot
+    // block 1 in panel 0's second interval and `extra2` (the affine right-hand side) in panel 1's; behind panel 0's barrier X every wave asks `stopped()` and the flag of pivot block 0: -1 = the loop stops
     // (the panel of speculative work is dropped), > 0 = pivot block 0 broke down.
-    template <int ROLE, bool kSweep, bool kA, class PanelInfo, class Extra1, class Extra2, class Stopped>
+    template <int ROLE, bool kSweep, bool kA, class PanelInfo, class Extra0, class Extra1, class Extra2, class Stopped>
     static QPX_DEV int factor_role_impl(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, int mrows, PanelInfo&& panel,
-                                        Extra1&& extra1, Extra2&& extra2, Stopped&& stopped)
+                                        Extra0&& extra0, Extra1&& extra1, Extra2&& extra2, Stopped&& stopped)
     {
         constexpr bool kChain = ROLE < 0;
         constexpr int W = kChain ? 0 : ROLE;
@@ -993,6 +1048,9 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) nrd[r] = -rd[16 * k + p.g + 4 * r];
                 if constexpr (kChain) {
+                    if constexpr (kA) {
+                        if (k == 0) extra0();
+                    }
                     if (la) {
                         // (two accumulators per product -- chains of two dependent MFMAs instead of four -- measured no
                         // gain: this interval waits for the tile waves' operand tiles anyway, profiles/archive/r03h)
@@ -1100,14 +1158,15 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     }
 
     // the loop kernel's factorisation with the chain wave ahead (kAhead): 0 = done, -1 = the loop stops, > 0 = breakdown
-    template <class P, class Extra1, class Extra2, class Stopped>
-    static QPX_DEV int ldl_inv_ahead(const Block& blk, const P& p, Regs& E, T* scr, T* rd, int m, Extra1&& extra1, Extra2&& extra2, Stopped&& stopped)
+    template <class P, class Extra0, class Extra1, class Extra2, class Stopped>
+    static QPX_DEV int ldl_inv_ahead(const Block& blk, const P& p, Regs& E, T* scr, T* rd, int m, Extra0&& extra0, Extra1&& extra1, Extra2&& extra2,
+                                     Stopped&& stopped)
     {
         static_assert(CH && role_of<P>::value >= -1, "chain-wave form: call through with_role");
         blk.template prio<3>();
         const int npan = (m + 15) / 16 < NBL ? (m + 15) / 16 : NBL;
         return factor_role_impl<role_of<P>::value, false, true>(blk, p, E, scr, rd, npan, m, [m](int k) { return PanelOf{m - 16 * k, 1}; },
-                                                               extra1, extra2, stopped);
+                                                               extra0, extra1, extra2, stopped);
     }
 
     // E: T (SPD, order m, padded with the identity) -> strictly lower: W~ = L~^-1, rd[k] = 1/d_k; false: a pivot

@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 S=$OUT/summary.txt
 : > $S
-for dims in "512 100 100 0" "512 100 50 10" "8192 64 64 0" "2048 100 100 0" "256 100 100 0"; do
+for dims in "512 100 100 0" "512 100 50 10" "8192 64 64 0" "256 100 100 0"; do
   echo "-- B n m q = $dims" >> $OUT/${TAG}_ab_r05.txt
   timeout 300 python scripts/ab_bench.py qpth_amd/libqpx_hip_r05.so qpth_amd/libqpx_hip.so $dims 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_ab_r05.txt
 done
