@@ -1128,6 +1128,10 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         QPX_PROF(1)
         Mat::template solve_neg<true>(b, g, E, rd, m, vRH, vX, vTm, scr);
         QPX_PROF(6)
+        // (The next pass's copy of R requested HERE by the tile waves -- their registers are free once the second solve has
+        // read them -- so that it arrives under the chain wave's step-length block: measured again in round 6 with the chain
+        // wave ahead, 0.4448 against 0.4428 ms, no gain -- profiles/r06g_ab_early_load_two_accumulators.txt; rounds 2 and 3
+        // had measured the same with their orders of a pass.)
         if (w0) ipm_final_step<T, NS>(b, lane, m, vZ, vS, vRZ, vRS, vD, vX, vRSC, vDZA, vDSA, vA, sc + kTau, sc + kAlphaPrev, sc[kSigz]);
         Mat::sync(b);
         QPX_PROF(1)
@@ -1338,6 +1342,7 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
     const In<T> ryg((!kBackward && q > 0) ? a.ry : nullptr, (size_t)qp * q, io32);
     const In<T> lamg(kBackward ? a.lam : nullptr, (size_t)qp * m, io32), slg(kBackward ? a.slack : nullptr, (size_t)qp * m, io32);
     const In<T> dg(kBackward ? nullptr : a.d, (size_t)qp * m, io32);
+    QPX_PROF_INIT
 
     for (int i = b.tid; i < n; i += NT) vRX[i] = rxg ? rxg[i] : T(0);
     for (int i = b.tid; i < q; i += NT) vRY[i] = ryg ? ryg[i] : T(0);
@@ -1378,14 +1383,32 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
         }
         Mat::sync(b);
     };
+    QPX_PROF(0)
     products(vRX, vRY, vRH, vDX);
+    QPX_PROF(1)
     // (round 5 tried the image of R requested BEFORE the products at seven tile rows, where the registers allow it, so that its
     // round trip to HBM runs under theirs: 1.5 us SLOWER at C2, 0.0499 vs 0.0485 ms, same box -- the image's 57 KB then
     // compete with the 160 KB the products stream.  profiles/r05f_ab_symv_prefetch_and_backward_load_order.txt)
     typename Mat::Regs E;
-    Mat::load(b, g, E, Mat::image(F, lay));
-    Mat::add_diag(g, E, vD);
-    const bool ok = Mat::ldl_inv(b, g, E, scr, rd, m);
+    bool ok;
+    if constexpr (Mat::kAhead) {
+        // (r6) chain-wave form: the chain wave eliminates pivot block 0 -- R(0,0) from its own five loads + 1/d -- while the
+        // tile waves fetch their 57 KB of R; one barrier in front of the panels instead of three (TileMat::kAhead)
+        typename Mat::Ahead ah;
+        Mat::ahead_init(b, g, ah, Mat::image(F, lay));
+        Mat::load(b, g, E, Mat::image(F, lay));
+        Mat::ahead_pivot0(b, g, ah, vD, scr, rd, m);
+        Mat::ahead_publish0(b, g, E, vD, scr);
+        Mat::sync(b);
+        QPX_PROF(2)
+        ok = Mat::ldl_inv_ahead(b, g, E, scr, rd, m, [] {}, [] {}, [] {}, [] { return 0; }) == 0;
+    } else {
+        Mat::load(b, g, E, Mat::image(F, lay));
+        Mat::add_diag(g, E, vD);
+        QPX_PROF(2)
+        ok = Mat::ldl_inv(b, g, E, scr, rd, m);
+    }
+    QPX_PROF(3)
     if (!ok && b.tid == 0 && a.status) a.status[qp] |= QPX_ST_KKT_BREAKDOWN;
     auto finish = [&](const T* rX, const T* rY, T* rH, T* oZ, T* oX, T* oY) {
         if (ok) Mat::solve_neg(b, g, E, rd, m, rH, oZ, vTm, scr);
@@ -1393,6 +1416,7 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
             for (int i = b.tid; i < M8; i += NT) oZ[i] = T(0);
             Mat::sync(b);
         }
+        QPX_PROF(4)
         // oX = Kneg rX - M^T oZ + NTn^T rY     (Kneg = -K, NTn = -N^T; the first term from above)
         block_matvec16<T, 2>(b, oX, F + lay.MT, oZ, n, m);
         if (q > 0) {
@@ -1413,6 +1437,7 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
         finish(rX, rY, rH, oZ, oX, oY);
     };
     finish(vRX, vRY, vRH, vDZ, vDX, vDY);
+    QPX_PROF(5)
 
     // Iterative refinement on the residual of the ORIGINAL KKT system (batch.py:244-270, solve_kkt_ir; the factor
     // is re-used, not re-computed as there):  res = K sol + rhs  with the caller's Q, G, A,  sol += K~^-1 (-res).
@@ -1498,6 +1523,8 @@ QPX_DEV void kkt_mat_role(const Block& b, const KktArgs<T>& a, int qp, T* lds, c
             put_(a.dA, io32, o + idx, vDY[r] * vZH[c] + vNU[r] * vDX[c]);
         }
     }
+    QPX_PROF(6)
+    QPX_PROF_DUMP(F + lay.prof, T)          // (profiling build only: the blob's timer words, scripts/prof_backward.py)
 }
 
 template <class T, class Mat, bool kBackward>

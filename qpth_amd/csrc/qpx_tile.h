@@ -567,6 +567,14 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             publish_rows<role_of<P>::value>(p0.fresh(), E, scr, 0, false);
         }
     }
+    // the same without a mat-vec (the KKT kernels: factor_kkt for a given d): T = R + diag(vd), panel 0's old rows -> X
+    template <class P> static QPX_DEV void ahead_publish0(const Block&, const P& p0, Regs& E, const T* vd, T* scr)
+    {
+        if constexpr (role_of<P>::value >= 0) {
+            add_diag(p0, E, vd);
+            publish_rows<role_of<P>::value>(p0.fresh(), E, scr, 0, false);
+        }
+    }
     // chain wave, behind that barrier: vout = R vin from the partials
     static QPX_DEV void ahead_gather(const Block& blk, int lane, const T* scr, T* vout)
     {
