@@ -79,8 +79,16 @@ QPX_LAYOUT_HD constexpr int tile_union_chain(int nbl, int nwm)      // chain-wav
 }
 // chain-wave form, behind the row buffer: S2 (256: the diagonal tile of the next pivot block but one)
 constexpr int kChainExtra = 256;
+// (r6) ONE wave per QP (not the chain-wave form): the operand tiles of a panel replace the panel's old rows in X where they
+// stand, and the mat-vec scratch -- used between factorisations only -- shares X's LDS: 26 KB instead of 36 per QP at four
+// tile rows, i.e. six workgroups on a CU instead of four (TileMat::kInPlace)
+QPX_LAYOUT_HD constexpr bool tile_in_place(int nwm, bool chain) { return !chain && nwm == 1; }
 QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nwm, bool chain = false)
 {
+    if (tile_in_place(nwm, chain)) {
+        const size_t x = (size_t)16 * tile_xs(nbl), u = (size_t)tile_union(nbl, 1);
+        return (x > u ? x : u) + 2 * 16 * 18 + 2 + 16 * (size_t)nbl;
+    }
     return (size_t)16 * tile_xs(nbl) + 2 * 16 * 18 + 2 + (chain ? tile_union_chain(nbl, nwm) : tile_union(nbl, nwm)) +
            16 * (size_t)nbl + (chain ? kChainExtra : 0);
 }
@@ -221,10 +229,20 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // tile after next).  XS = 17 mod 32 and SS = 18 keep both the row-wise and the transposed accesses
     // (lane stride XS resp. SS doubles) on distinct LDS banks.
     static constexpr int XS = tile_xs(NBL), SS = 18;
-    static constexpr int kX = 0, kS = 16 * XS, kW = kS + 16 * SS, kFlag = kW + 16 * SS, kPart = kFlag + 2;
+    // kInPlace (one wave per QP): operand tile b_J is written over X_J -- same shape, same (row, column) addressing, the
+    // wave that reads X_J is the one that writes b_J -- and { part | red } lie on top of X (they live between
+    // factorisations, X inside one): no BT, no separate mat-vec scratch.
+    static constexpr bool kInPlace = tile_in_place(NWM, CH);
+    static constexpr int kXEnd = kInPlace ? (16 * XS > tile_union(NBL, NWM) ? 16 * XS : tile_union(NBL, NWM)) : 16 * XS;
+    static constexpr int kX = 0, kS = kXEnd, kW = kS + 16 * SS, kFlag = kW + 16 * SS, kPart = kInPlace ? 0 : kFlag + 2;
     static constexpr int kRed = kPart + NWM * NBL * 64, kBT = kPart, kAT = kBT + NBL * 256;
-    static constexpr int kRow = kPart + (CH ? tile_union_chain(NBL, NWM) : tile_union(NBL, NWM));
+    static constexpr int kRow = kInPlace ? kFlag + 2 : kPart + (CH ? tile_union_chain(NBL, NWM) : tile_union(NBL, NWM));
     static constexpr int kS2 = kRow + MP;
+    // operand tile J, register r of lane p: where it is kept between the operand phase and the update
+    static QPX_DEV int bt_at(const Pos& p, int J, int r)
+    {
+        return kInPlace ? kX + (p.g + 4 * r) * XS + 16 * J + p.c : kBT + J * 256 + r * 64 + p.lane;
+    }
     QPX_LAYOUT_HD static size_t scratch_elems() { return (size_t)kRow + MP + (CH ? kChainExtra : 0); }
     static QPX_DEV void sync(const Block& blk)
     {
@@ -679,7 +697,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                 for (int r = 0; r < 4; ++r) aop[pp][r] = T(0);
                 if (I <= Ip) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) aop[pp][r] = BT[I * 256 + r * 64 + p.lane] * nrd[r];
+                for (int r = 0; r < 4; ++r) aop[pp][r] = scr[bt_at(p, I, r)] * nrd[r];
             }
         }
 #pragma unroll
@@ -689,7 +707,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             for (int J = 0; J < psize(pp); ++J) {
                 if (J > Ip) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) E.e[slot(pp, J)][r] = BT[J * 256 + r * 64 + p.lane];
+                for (int r = 0; r < 4; ++r) E.e[slot(pp, J)][r] = scr[bt_at(p, J, r)];
             }
         }
 #pragma unroll
@@ -704,7 +722,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             if (!need) continue;
             T bj[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bj[r] = BT[J * 256 + r * 64 + p.lane];
+            for (int r = 0; r < 4; ++r) bj[r] = scr[bt_at(p, J, r)];
             // the panel's own columns restart from zero (their old values went into X): multiplied by a factor that is
             // 0 there and 1 elsewhere, outside every branch
             const T keep = J == Ip ? zr : T(1);
@@ -972,7 +990,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                 T acc[4];
                 operand_tile(blk, p, scr, Ip, J, wa, acc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) BT[J * 256 + r * 64 + p.lane] = acc[r];
+                for (int r = 0; r < 4; ++r) scr[bt_at(p, J, r)] = acc[r];
             }
         }
         QPX_PP(3)
