@@ -271,13 +271,13 @@ template <class T, int GS, int NBL> struct GridMat {
     }
 };
 
-// LDS elements of the loop kernel: 20 vectors of v = align4(max(n, MP, q)), 16 scalars + 8 control
+// LDS elements of the loop kernel: 17 vectors of v = 64 NS >= max(n, MP, q), 16 scalars + 8 control
 // words, scratch
 QPX_LAYOUT_HD size_t lds_elems_ipm_loop(size_t mp, size_t scratch, int n, int q)
 {
     const size_t d = max2(max2((size_t)n, mp), (size_t)q);
     const size_t v = d <= 64 ? 64 : (d <= 128 ? 128 : (d <= 256 ? 256 : 512));    // 64 NS, see ipm_loop_body
-    return 20 * v + 24 + scratch;
+    return 17 * v + 24 + scratch;
 }
 QPX_LAYOUT_HD size_t lds_elems_ipm_grid(int gs, int nbl, int n, int q)
 {
@@ -916,16 +916,18 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
     T* vD = vR1 + v;      // s/z, 1 on the pad (M8)
     T* vBZ = vD + v;      // best z
     T* vBS = vBZ + v;     // best s
-    T* vRH = vBS + v;     // right-hand side of a solve (M8, zero padded)
-    T* vX = vRH + v;      // its solution
+    // (r6) seventeen vectors, not twenty: three share LDS with one whose life does not overlap theirs -- at one wave per
+    // QP and four tile rows those 1.5 KB decide between six and eight workgroups on a CU (qpx_tile.h: kInPlace)
+    T* vRH = vB;          // right-hand side of a solve (M8, zero padded): formed FROM R z' element by element, in place
+    T* vX = vBS + v;      // its solution
     T* vTm = vX + v;      // scratch of the solve
-    T* vP = vTm + v;      // p / b staging (n)
-    T* vZ = vP + v;       // z, s and their reciprocals
+    T* vP = vX;           // p staging (n): read by the two products in front of the loop only; vX is first written behind them
+    T* vZ = vTm + v;      // z, s and their reciprocals
     T* vS = vZ + v;
     T* vRZ = vS + v;
     T* vRS = vRZ + v;
-    T* vDZA = vRS + v;    // affine step, corrector right-hand side rs
-    T* vDSA = vDZA + v;
+    T* vDZA = vA;         // affine step: written behind the mat-vec (the last reader of z' in a pass), read by the block that then writes the new z'
+    T* vDSA = vRS + v;    // ... and the corrector right-hand side rs
     T* vRSC = vDSA + v;
     T* vX0 = vRSC + v;    // x0 = -K p (n): formed with c at the start, while p's products share their loads' flight
     T* sc = vX0 + v;                                // 16 scalars of the IPM state
@@ -960,7 +962,6 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         vC[i] = (i < m) ? hg[i] : T(0);
         vD[i] = T(1);
         vA[i] = T(1);                     // first use: R 1
-        vRH[i] = T(0);
     }
     Mat::sync(b);
     block_matTvec2<T, 1, 0>(b, vC, F + lay.MT, m, vX0, F + lay.Kneg, n, vP, n);      // c += M p;  x0 = -K p
@@ -992,7 +993,7 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
     }
     for (int i = b.tid; i < M8; i += NT) {
         vZ[i] = T(1); vS[i] = T(1); vRZ[i] = T(1); vRS[i] = T(1);
-        vDZA[i] = T(0); vDSA[i] = T(0); vRSC[i] = T(0);
+        vDSA[i] = T(0); vRSC[i] = T(0);
     }
     Mat::sync(b);
 
@@ -1281,7 +1282,7 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         for (int r = b.tid; r < q; r += NT) {
             T acc = 0;
             for (int c2 = 0; c2 < q; ++c2) acc = fma_(-F[lay.S11i + (size_t)r * q + c2], vTm[c2], acc);
-            for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], vP[k], acc);
+            for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], pg[k], acc);      // (p from the caller's array: its staging vector is long gone)
             for (int j = 0; j < m; ++j) acc = fma_(-F[lay.W + (size_t)j * q + r], vA[j], acc);
             put_(a.nu, io32, (size_t)qp * q + r, acc);
         }

@@ -80,15 +80,22 @@ QPX_LAYOUT_HD constexpr int tile_union_chain(int nbl, int nwm)      // chain-wav
 // chain-wave form, behind the row buffer: S2 (256: the diagonal tile of the next pivot block but one)
 constexpr int kChainExtra = 256;
 // (r6) ONE wave per QP (not the chain-wave form): the operand tiles of a panel replace the panel's old rows in X where they
-// stand, and the mat-vec scratch -- used between factorisations only -- shares X's LDS: 26 KB instead of 36 per QP at four
-// tile rows, i.e. six workgroups on a CU instead of four (TileMat::kInPlace)
+// stand, and everything the mat-vecs need between two factorisations lies on top of what a factorisation needs -- the
+// row-sum scratch and the row sums on X, the column partials on the one buffer the pivot block goes in by and comes out of
+// (S and W: one wave reads the block before it writes the factor).  With X's rows 9 mod 32 apart and the pivot block's 17
+// that is 11.7 KB of scratch instead of 26 at four tile rows: with the loop's vectors 20.4 KB per QP, EIGHT workgroups on
+// a CU (two to a SIMD; LDS is dealt in two halves of 80 KB, so it is 4, 6 or 8) instead of four.  TileMat::kInPlace.
 QPX_LAYOUT_HD constexpr bool tile_in_place(int nwm, bool chain) { return !chain && nwm == 1; }
+QPX_LAYOUT_HD constexpr int tile_xs_in_place(int nbl) { return ((16 * nbl - 9 + 31) / 32) * 32 + 9; }
+QPX_LAYOUT_HD constexpr int tile_x_end_in_place(int nbl)       // X = 16 rows; { red | yrow } on top of it
+{
+    const int x = 16 * tile_xs_in_place(nbl), r = 16 * nbl * 17 + 16 * nbl;
+    return x > r ? x : r;
+}
+QPX_LAYOUT_HD constexpr int tile_sw_in_place(int nbl) { return 16 * 17 > nbl * 64 ? 16 * 17 : nbl * 64; }     // S = W; part on top
 QPX_LAYOUT_HD constexpr size_t tile_scratch_elems(int nbl, int nwm, bool chain = false)
 {
-    if (tile_in_place(nwm, chain)) {
-        const size_t x = (size_t)16 * tile_xs(nbl), u = (size_t)tile_union(nbl, 1);
-        return (x > u ? x : u) + 2 * 16 * 18 + 2 + 16 * (size_t)nbl;
-    }
+    if (tile_in_place(nwm, chain)) return (size_t)tile_x_end_in_place(nbl) + tile_sw_in_place(nbl) + 2;
     return (size_t)16 * tile_xs(nbl) + 2 * 16 * 18 + 2 + (chain ? tile_union_chain(nbl, nwm) : tile_union(nbl, nwm)) +
            16 * (size_t)nbl + (chain ? kChainExtra : 0);
 }
@@ -228,22 +235,26 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // tiles; chain-wave form: + AT, the same tiles times -1/d) | yrow (MP) | chain-wave form: S2 (256: the diagonal
     // tile after next).  XS = 17 mod 32 and SS = 18 keep both the row-wise and the transposed accesses
     // (lane stride XS resp. SS doubles) on distinct LDS banks.
-    static constexpr int XS = tile_xs(NBL), SS = 18;
     // kInPlace (one wave per QP): operand tile b_J is written over X_J -- same shape, same (row, column) addressing, the
-    // wave that reads X_J is the one that writes b_J -- and { part | red } lie on top of X (they live between
-    // factorisations, X inside one): no BT, no separate mat-vec scratch.
+    // wave that reads X_J is the one that writes b_J --; S and W are one buffer; { red | yrow } lie on top of X and the
+    // column partials on top of S / W (they live between factorisations, X, S and W inside one): no BT, no mat-vec scratch
+    // of its own (tile_scratch_elems).
     static constexpr bool kInPlace = tile_in_place(NWM, CH);
-    static constexpr int kXEnd = kInPlace ? (16 * XS > tile_union(NBL, NWM) ? 16 * XS : tile_union(NBL, NWM)) : 16 * XS;
-    static constexpr int kX = 0, kS = kXEnd, kW = kS + 16 * SS, kFlag = kW + 16 * SS, kPart = kInPlace ? 0 : kFlag + 2;
-    static constexpr int kRed = kPart + NWM * NBL * 64, kBT = kPart, kAT = kBT + NBL * 256;
-    static constexpr int kRow = kInPlace ? kFlag + 2 : kPart + (CH ? tile_union_chain(NBL, NWM) : tile_union(NBL, NWM));
+    static constexpr int XS = kInPlace ? tile_xs_in_place(NBL) : tile_xs(NBL), SS = kInPlace ? 17 : 18;
+    static constexpr int kXEnd = kInPlace ? tile_x_end_in_place(NBL) : 16 * XS;
+    static constexpr int kX = 0, kS = kXEnd, kW = kInPlace ? kS : kS + 16 * SS;
+    static constexpr int kFlag = kInPlace ? kS + tile_sw_in_place(NBL) : kW + 16 * SS;
+    static constexpr int kPart = kInPlace ? kS : kFlag + 2;
+    static constexpr int kRed = kInPlace ? 0 : kPart + NWM * NBL * 64, kBT = kPart, kAT = kBT + NBL * 256;
+    static constexpr int kRow = kInPlace ? NWM * NROW * 17 : kPart + (CH ? tile_union_chain(NBL, NWM) : tile_union(NBL, NWM));
     static constexpr int kS2 = kRow + MP;
+    static_assert(!kInPlace || (kRow + MP <= kXEnd && NWM * NBL * 64 <= tile_sw_in_place(NBL) && NROW == 16 * NBL), "one-wave layout");
     // operand tile J, register r of lane p: where it is kept between the operand phase and the update
     static QPX_DEV int bt_at(const Pos& p, int J, int r)
     {
         return kInPlace ? kX + (p.g + 4 * r) * XS + 16 * J + p.c : kBT + J * 256 + r * 64 + p.lane;
     }
-    QPX_LAYOUT_HD static size_t scratch_elems() { return (size_t)kRow + MP + (CH ? kChainExtra : 0); }
+    QPX_LAYOUT_HD static size_t scratch_elems() { return kInPlace ? (size_t)kFlag + 2 : (size_t)kRow + MP + (CH ? kChainExtra : 0); }
     static QPX_DEV void sync(const Block& blk)
     {
         if (NW == 1) blk.wave_sync();
