@@ -921,7 +921,7 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
     T* vRH = vB;          // right-hand side of a solve (M8, zero padded): formed FROM R z' element by element, in place
     T* vX = vBS + v;      // its solution
     T* vTm = vX + v;      // scratch of the solve
-    T* vP = vX;           // p staging (n): read by the two products in front of the loop only; vX is first written behind them
+    T* vP = vX;           // p staging (n): read by the two products in front of the loop only (vX is first written behind them); the epilogue stages p again, in vRZ
     T* vZ = vTm + v;      // z, s and their reciprocals
     T* vS = vZ + v;
     T* vRZ = vS + v;
@@ -1264,8 +1264,10 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
             put_(a.best_resid, io32, (size_t)qp, bres);
         }
     }
-    if (q > 0)
+    if (q > 0) {
         for (int i = b.tid; i < q; i += NT) vTm[i] = bg[i];
+        for (int i = b.tid; i < n; i += NT) vRZ[i] = pg[i];      // p once more (nu needs it; its staging vector of the prologue is long gone): 1/z is not needed any more
+    }
     Mat::sync(b);
     // zhat = x0 - M^T z' = -K p + N b - M^T z'
     for (int i = b.tid; i < n; i += NT) vX[i] = vX0[i];
@@ -1282,7 +1284,7 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
         for (int r = b.tid; r < q; r += NT) {
             T acc = 0;
             for (int c2 = 0; c2 < q; ++c2) acc = fma_(-F[lay.S11i + (size_t)r * q + c2], vTm[c2], acc);
-            for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], pg[k], acc);      // (p from the caller's array: its staging vector is long gone)
+            for (int k = 0; k < n; ++k) acc = fma_(F[lay.NTn + (size_t)r * n + k], vRZ[k], acc);
             for (int j = 0; j < m; ++j) acc = fma_(-F[lay.W + (size_t)j * q + r], vA[j], acc);
             put_(a.nu, io32, (size_t)qp * q + r, acc);
         }

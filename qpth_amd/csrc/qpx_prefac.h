@@ -33,10 +33,13 @@ namespace qpx {
 constexpr int kPfVS = 16 * 17;                          // one tile of V in LDS
 QPX_LAYOUT_HD constexpr int prefac_cap(int nbn) { return nbn == 7 ? 5 : 7; }     // blocks of Yt that fit in LDS beside the rest
 QPX_LAYOUT_HD constexpr size_t prefac_fixed_elems(int nbn) { return (size_t)16 * nbn + 8 + 7 * 16 * (size_t)nbn; }
-QPX_LAYOUT_HD constexpr size_t lds_elems_prefac_tile(int nbn)
+// nbm: the m-blocks there are (blocks of Yt beyond them are never staged).  (r6: sized by prefac_cap alone the kernel took
+// 61 KB at four tile rows whatever nineq -- one workgroup per 80 KB half of a CU's LDS; with nineq <= 64 it is 40.9 KB, two.)
+QPX_LAYOUT_HD constexpr size_t lds_elems_prefac_tile(int nbn, int nbm = 1 << 20)
 {
+    const int slots = nbm < prefac_cap(nbn) ? nbm : prefac_cap(nbn);
     const size_t scr = tile_scratch_elems(nbn, 3, true), vs = (size_t)(nbn * (nbn + 1) / 2) * kPfVS,
-                 yb = (size_t)prefac_cap(nbn) * nbn * 256;
+                 yb = (size_t)slots * nbn * 256;
     const size_t u = scr > vs ? (scr > yb ? scr : yb) : (vs > yb ? vs : yb);
     return prefac_fixed_elems(nbn) + u;
 }

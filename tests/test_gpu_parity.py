@@ -506,8 +506,9 @@ def test_c5_shard_matches_oracle_and_kkt(dev):
 
 def test_c5_shape_beyond_8192_qps_runs_the_one_wave_form(dev):
     """The dispatcher switches the C5 shape (nz = nineq = 64: four tile rows) from the chain-wave form to one wave per QP
-    beyond 8 192 QPs per launch (qpx_api.inc: tile_waves; BASELINE.json configs[4] on ONE GPU is 65 536).  VERDICT r3: only
-    the <= 8 192 side was exercised at size.  9 216 QPs: every 36th against the oracle (batch-of-one semantics, so the
+    beyond 512 QPs per launch (round 6; 8 192 until then -- qpx_api.inc: tile_waves; BASELINE.json configs[4] on ONE GPU is
+    65 536), where the one-wave kernels keep eight workgroups on a CU (20 KB of LDS each: operand tiles in place of the
+    panel's rows, S = W, the mat-vec scratch on the factorisation's).  VERDICT r3: only the <= 8 192 side was exercised at size.  9 216 QPs: every 36th against the oracle (batch-of-one semantics, so the
     subset is the same problem), the KKT conditions of all, and the p-gradient of the subset."""
     from oracle import qp_oracle as orc
     from qpth_amd.kkt import KKTFactors

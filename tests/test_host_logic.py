@@ -73,3 +73,47 @@ def test_sharded_solves_refuse_what_cannot_be_sharded():
     with pytest.raises(RuntimeError, match="nothing to shard"):
         qdist.check_shardable([Q, torch.zeros(3), torch.ones(1, 3), torch.ones(1), e, e], 8, 2)
     qdist.check_shardable([Q, torch.zeros(8, 3), torch.ones(1, 3), torch.ones(1), e, e], 8, 2)
+
+
+def test_pinned_status_buffers_are_never_handed_out_twice():
+    """qpth_amd.kkt._PinnedPool (round 6; until then a process-global ring with an unsynchronised index that silently
+    reused a buffer after 16 outstanding builds): a buffer belongs to one owner from take() to give(); a buffer given up
+    while its copy is still in flight comes back only once its event has completed; an event that cannot be asked
+    (recorded inside a stream capture) drops the buffer."""
+    import torch
+    from qpth_amd import kkt
+
+    class Ev:
+        def __init__(self, done):
+            self.done = done
+
+        def query(self):
+            if self.done is None:
+                raise RuntimeError("captured event")
+            return self.done
+
+    pool = kkt._PinnedPool()
+    dev = torch.device("cuda", 0)
+    made = []
+    real = torch.Tensor.pin_memory
+    torch.Tensor.pin_memory = lambda t: (made.append(t) or t)          # (no HIP runtime here: a pinned buffer is just a tensor)
+    try:
+        k1, a = pool.take(dev, 8)
+        k2, b = pool.take(dev, 8)
+        assert a is not b and len(made) == 2                           # two outstanding owners: two buffers
+        pool.give(k1, a)                                               # read and returned
+        k3, c = pool.take(dev, 8)
+        assert c is a and len(made) == 2                               # reused only after it was given back
+        ev = Ev(False)
+        pool.give(k2, b, ev)                                           # owner died with the copy in flight
+        k4, d = pool.take(dev, 8)
+        assert d is not b and len(made) == 3                           # not handed out while in flight
+        ev.done = True
+        k5, e = pool.take(dev, 8)
+        assert e is b                                                  # ... and back once the event has completed
+        pool.give(k5, e, Ev(None))                                     # an event that cannot be asked: dropped
+        k6, f = pool.take(dev, 8)
+        assert f is not e and len(made) == 4
+        assert pool.take(dev, 16)[1].numel() == 16                     # another size: another list
+    finally:
+        torch.Tensor.pin_memory = real
