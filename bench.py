@@ -355,6 +355,7 @@ def main():
         B, global_B = Bcfg, Bcfg * world
     host, (tQ, tp, tG, th, tA, tb) = make_batch(B, n, m, q, rank, np_dt, dev)
     if args.shared:
+        torch.manual_seed(1234 + rank)        # (the launch lasts as long as its slowest QP: unseeded data moved the line by 10 % between runs)
         tQ, tG = tQ[0].contiguous(), tG[0].contiguous()
         tz0 = torch.randn(B, n, dtype=tQ.dtype, device=dev)
         th = tz0 @ tG.t() + torch.rand(B, m, dtype=tQ.dtype, device=dev)

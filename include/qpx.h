@@ -123,9 +123,9 @@ int qpx_refine_supported(int dtype, int n, int m, int q);
  * -- that lost their A/Bs and were deleted.)
  * Large-QP family only: bits 16..19 = number of parts (1..4) the batch is split into, each part enqueued on a
  * stream of its own (the caller's + side streams forked from and joined back into it with events; the one host wait
- * this can involve is described under "Conventions"), 0 = automatic: two parts from 96 QPs up, else one -- in every
- * entry point that runs the family's launch sequence (qpx_pre_factor, qpx_ipm / qpx_forward, qpx_factor_solve_kkt,
- * qpx_backward, qpx_polish); bits 20..24 = initial stagger between the side streams in units of 16 us; (bit 25 selected
+ * this can involve is described under "Conventions"), 0 = automatic: two parts from 96 QPs up, else one, in
+ * qpx_pre_factor, qpx_ipm / qpx_forward and qpx_polish; one part in qpx_factor_solve_kkt / qpx_backward (one factorisation +
+ * one solve is too short a sequence to gain: profiles/r06q_backward_parts.txt), which take parts only from an explicit value; bits 20..24 = initial stagger between the side streams in units of 16 us; (bit 25 selected
  * the four-wave substitutions of round 3 until v7: retired with them); bit 26 = the mat-vec R z' in front of the factorisation
  * in the caller's stream (the round-3 order) instead of beside it on a helper stream; bit 27 =
  * diagonal blocks eliminated by one wave (the round-3 form) instead of four in the chain-wave form; bit 28 = on the
