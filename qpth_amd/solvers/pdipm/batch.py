@@ -157,6 +157,37 @@ def factor_solve_kkt_reg(Q_tilde, D, G, A, rx, rs, rz, ry, eps):
     ds = (-rs_ - dz) / (d if d.dim() == 2 else d.unsqueeze(0))      # the second block row with the caller's d
     return dx, ds, dz, dy
 
+def unpack_kkt(v, nz, nineq, neq):
+    """unpack_kkt (batch.py:216-225): the stacked KKT vector (x, s, z, y) -> its four parts (views)."""
+    x = v[:, :nz]
+    s = v[:, nz:nz + nineq]
+    z = v[:, nz + nineq:nz + 2 * nineq]
+    y = v[:, nz + 2 * nineq:nz + 2 * nineq + neq]
+    return x, s, z, y
+
+
+def kkt_resid_reg(Q_tilde, D_tilde, G, A, eps, dx, ds, dz, dy, rx, rs, rz, ry):
+    """kkt_resid_reg (batch.py:228-241): the residual of (dx, ds, dz, dy) in the regularised KKT system
+        Q~ dx + G^T dz + A^T dy + rx,   D~ ds + dz + rs,   G dx + ds - eps dz + rz,   A dx - eps dy + ry,
+    D_tilde a (nBatch, nineq, nineq) matrix as in the reference, dy / ry None without equality constraints.  A DIAGNOSTIC
+    helper kept for callers of the reference's module surface: nothing on the product path calls it -- the kernels that
+    refine (qpx_factor_solve_kkt(..., refine), qpx_polish) form this residual themselves, in float64 accumulation -- and it
+    is the one function of this file that is plain tensor arithmetic (broadcast products, no library calls)."""
+    def mv(M, v):            # (B, r, c) x (B, c) -> (B, r)
+        return (M * v.unsqueeze(1)).sum(2)
+
+    def mtv(M, v):           # (B, r, c)^T x (B, r) -> (B, c)
+        return (M * v.unsqueeze(2)).sum(1)
+
+    resx = mv(Q_tilde, dx) + mtv(G, dz) + rx
+    if dy is not None:
+        resx = resx + mtv(A, dy)
+    ress = mv(D_tilde, ds) + dz + rs
+    resz = mv(G, dx) + ds - eps * dz + rz
+    resy = mv(A, dx) - eps * dy + ry if dy is not None else None
+    return resx, ress, resz, resy
+
+
 def forward(Q, p, G, h, A, b, Q_LU, S_LU, R, eps=1e-12, verbose=0, notImprovedLim=3,
             maxIter=20, solver=KKTSolvers.LU_PARTIAL, stall_policy=None):
     """

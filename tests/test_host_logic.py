@@ -117,3 +117,41 @@ def test_pinned_status_buffers_are_never_handed_out_twice():
         assert pool.take(dev, 16)[1].numel() == 16                     # another size: another list
     finally:
         torch.Tensor.pin_memory = real
+
+
+def test_unpack_kkt_and_kkt_resid_reg_mirror_the_reference():
+    """batch.py:216-241: the two helpers of the reference's module surface that have no kernel of their own (the kernels
+    that refine form the residual themselves).  A dense solve of the regularised KKT system has residual ~0 under
+    kkt_resid_reg; a perturbed one has exactly the perturbation's image."""
+    import numpy as np
+    import torch
+    from qpth_amd.solvers.pdipm import batch as pb
+    rng = np.random.RandomState(3)
+    B, nz, nineq, neq, eps = 3, 6, 4, 2, 1e-3
+    L = rng.rand(B, nz, nz)
+    Q = L @ L.transpose(0, 2, 1) + 0.1 * np.eye(nz)
+    d = rng.rand(B, nineq) + 0.5
+    D = np.stack([np.diag(x) for x in d])
+    G, A = rng.randn(B, nineq, nz), rng.randn(B, neq, nz)
+    rx, rs, rz, ry = rng.randn(B, nz), rng.randn(B, nineq), rng.randn(B, nineq), rng.randn(B, neq)
+    sols = []
+    for i in range(B):
+        K = np.zeros((nz + 2 * nineq + neq,) * 2)
+        K[:nz, :nz] = Q[i]; K[:nz, nz + nineq:nz + 2 * nineq] = G[i].T; K[:nz, nz + 2 * nineq:] = A[i].T
+        K[nz:nz + nineq, nz:nz + nineq] = D[i]; K[nz:nz + nineq, nz + nineq:nz + 2 * nineq] = np.eye(nineq)
+        K[nz + nineq:nz + 2 * nineq, :nz] = G[i]; K[nz + nineq:nz + 2 * nineq, nz:nz + nineq] = np.eye(nineq)
+        K[nz + nineq:nz + 2 * nineq, nz + nineq:nz + 2 * nineq] = -eps * np.eye(nineq)
+        K[nz + 2 * nineq:, :nz] = A[i]; K[nz + 2 * nineq:, nz + 2 * nineq:] = -eps * np.eye(neq)
+        sols.append(np.linalg.solve(K, -np.concatenate([rx[i], rs[i], rz[i], ry[i]])))
+    v = torch.tensor(np.stack(sols))
+    dx, ds, dz, dy = pb.unpack_kkt(v, nz, nineq, neq)
+    assert dx.shape == (B, nz) and ds.shape == (B, nineq) and dz.shape == (B, nineq) and dy.shape == (B, neq)
+    t = lambda a: torch.tensor(a)
+    res = pb.kkt_resid_reg(t(Q), t(D), t(G), t(A), eps, dx, ds, dz, dy, t(rx), t(rs), t(rz), t(ry))
+    assert max(float(r.abs().max()) for r in res) < 1e-10
+    bump = torch.zeros_like(dz); bump[:, 0] = 1.0
+    res2 = pb.kkt_resid_reg(t(Q), t(D), t(G), t(A), eps, dx, ds, dz + bump, dy, t(rx), t(rs), t(rz), t(ry))
+    assert torch.allclose(res2[0], t(G)[:, 0, :], atol=1e-10) and torch.allclose(res2[1], bump, atol=1e-10)
+    assert torch.allclose(res2[2], -eps * bump, atol=1e-10)
+    rx3, rs3, rz3, _ = pb.kkt_resid_reg(t(Q), t(D), t(G), None, eps, dx, ds, dz, None, t(rx), t(rs), t(rz), None)
+    assert _ is None and rx3.shape == (B, nz)
