@@ -1009,8 +1009,8 @@ QPX_DEV void ipm_loop_role(const Block& b, const IpmArgs<T>& a, int qp, T* lds, 
     // the previous pass ends, so the chain wave eliminates pivot block 0 while the tile waves load R and form R z', and the
     // residual / best-iterate / stop bookkeeping runs on it in panel 0's second interval, beside the tile waves' longest
     // stretch of updates.  The stop decision is read by every wave behind that panel's last barrier; the panel the waves
-    // ran ahead of it on a pass that stops is dropped (T lives in registers nobody reads again).  Mathematics, order of
-    // the floating-point operations and results: those of the order below.
+    // ran ahead of it on a pass that stops is dropped (T lives in registers nobody reads again).  Mathematics and the order of
+    // the floating-point operations as written: those of the order below.
     typename Mat::Ahead ah;
     Mat::ahead_init(b, g, ah, Rg);
     for (int it = -1; it < a.maxIter && !stop; ++it) {
