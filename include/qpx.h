@@ -93,7 +93,7 @@ const char* qpx_strerror(int code);
 /* elements (of dtype) of factor storage per QP (C2, f64: 27 100 = 217 KB; B = 65536, n = m = 64: 5.5 GB) */
 size_t qpx_factor_elems(int dtype, int n, int m, int q);
 
-/* largest max(n,m,q) this build can solve */
+/* largest max(n,m,q) this build can solve (1 024 since round 6; qpx_polish: 512, see qpx_polish_supported) */
 int qpx_max_dim(void);
 /* QPX_OK if (dtype, n, m, q) is served under the calling thread's knob, else the QPX_ERR_* the entry points would
  * return (QPX_F32_WIDE: QPX_ERR_UNSUPPORTED outside the thread-grid / tile kernels' sizes) */
@@ -207,8 +207,8 @@ int qpx_backward(int dtype, int B, int n, int m, int q, void* factors, int64_t s
  * iterate met (the reference's rule, batch.py:118-139: residual ||rx|| + ||rz|| + ||ry|| + nineq mu, strict <, NaN never
  * wins; the start iterate competes), best_resid (dtype[B], may be NULL) with its residual.  Served by every kernel
  * family since v7 (dtype QPX_F32 or QPX_F64; one kernel up to nz+neq+nineq = 208, the large-QP family's launch sequence
- * beyond, where `refine` must be 0: qpx_refine_supported); qpx_polish_supported says so; QPX_F32_WIDE and sizes beyond
- * qpx_max_dim(): QPX_ERR_UNSUPPORTED.  Strides as everywhere: elements, 0 = shared by the batch. */
+ * beyond, where `refine` must be 0: qpx_refine_supported, and up to max(n,m,q) = 512 only: its vectors live in LDS);
+ * qpx_polish_supported says so; QPX_F32_WIDE and sizes beyond that: QPX_ERR_UNSUPPORTED.  Strides as everywhere: elements, 0 = shared by the batch. */
 int qpx_polish_supported(int dtype, int n, int m, int q);
 int qpx_polish(int dtype, int B, int n, int m, int q,
                const void* Q, int64_t sQ, const void* p, int64_t sp, const void* G, int64_t sG, const void* h, int64_t sh,

@@ -540,7 +540,9 @@ constexpr int kTrsvRows = kBB / kTrsvNW;       // rows of a block a wave owns
 constexpr int kTrsvPrefetch = 2;               // off-diagonal blocks of a step fetched one step ahead
 QPX_LAYOUT_HD size_t big_trsv_lds_elems(int np) { return (size_t)np + (size_t)(kTrsvNW + 1) * kBB; }
 
-template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<T>& a, int qp, T* lds)
+// kLong (r6): more than eight blocks of 64 (beyond 512 unknowns): a step's streamed blocks come in rounds of MS.  A separate
+// instantiation: with the rounds in the kernel the sizes up to 512 paid 1.5 - 14 % (registers of a sixteen-wave workgroup).
+template <class T, bool kLong = false> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<T>& a, int qp, T* lds)
 {
     if (a.check_stop && a.ctrl && (a.ctrl + (size_t)qp * a.sctrl)[bcStop]) return;
     constexpr int NW = kTrsvNW, RW = kTrsvRows, PF = kTrsvPrefetch, MS = 512 / kBB - 1 - kTrsvPrefetch;      // (MS: streamed blocks of a step at the largest size)
@@ -616,7 +618,7 @@ template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<
         };
         // the blocks beyond the prefetched ones: ALL their loads at once (at most five blocks = twenty loads per lane at the
         // largest size) -- in pairs, the largest steps were three dependent round trips to HBM long
-        {
+        if constexpr (!kLong) {
             T ms[MS][RW];
 #pragma unroll
             for (int j = 0; j < MS; ++j)
@@ -624,6 +626,16 @@ template <class T> QPX_DEV void big_trsv_body(const Block& b, const BigTrsvArgs<
 #pragma unroll
             for (int j = 0; j < MS; ++j)
                 if (PF + j < nblk) mac(PF + j, ms[j]);
+        } else {
+            for (int j0 = PF; j0 < nblk; j0 += MS) {
+                T ms[MS][RW];
+#pragma unroll
+                for (int j = 0; j < MS; ++j)
+                    if (j0 + j < nblk) ld_rows(rows_of(k, j0 + j), ms[j]);
+#pragma unroll
+                for (int j = 0; j < MS; ++j)
+                    if (j0 + j < nblk) mac(j0 + j, ms[j]);
+            }
         }
 #pragma unroll
         for (int jb = 0; jb < PF; ++jb)
@@ -675,8 +687,10 @@ template <class T> struct BigGemvArgs {
     T alpha, beta;
     const int* ctrl; size_t sctrl; int check_stop;
 };
-// LDS: the vector x (up to 512 elements) + 4 x 64 partial sums
-QPX_LAYOUT_HD size_t big_gemv_lds_elems() { return (size_t)8 * kBB + 4 * kWave; }
+// LDS: the vector x (up to 1 024 elements) + 4 x 64 partial sums
+// (sized by the vector there is: eight blocks up to 512 -- the measured footprint --, sixteen beyond)
+QPX_LAYOUT_HD int big_gemv_x_blocks(int nx) { return nx <= 8 * kBB ? 8 : 16; }
+QPX_LAYOUT_HD size_t big_gemv_lds_elems(int nx) { return (size_t)big_gemv_x_blocks(nx) * kBB + 4 * kWave; }
 #ifndef QPX_BIG_GEMV_ROWS
 #define QPX_BIG_GEMV_ROWS 4          // rows a wave works on at once (x two column blocks: loads in flight per lane)
 #endif
@@ -693,7 +707,7 @@ template <class T> QPX_DEV void big_gemv_body(const Block& b, const BigGemvArgs<
     // beside it -- 3.7 TB/s on a part whose plain streaming read reaches 5.7 (scripts/bw_probe.py).  Now x sits in LDS
     // and a wave keeps RB rows x 2 column blocks = eight independent loads in flight.
     T* xl = lds;                                 // x, padded with zeros to whole blocks of 64
-    T* part = lds + 8 * kBB;
+    T* part = lds + big_gemv_x_blocks(a.trans ? a.rows : a.cols) * kBB;
     const int nx = a.trans ? a.rows : a.cols, nxp = (nx + kBB - 1) / kBB * kBB;
     for (int i = b.tid; i < nxp; i += b.nt) xl[i] = i < nx ? x[i] : T(0);
     b.sync();
@@ -1272,10 +1286,10 @@ template <class T, int NS> QPX_DEV void big_solve_body(const Block& b, const Big
     }
     BigTrsvArgs<T> t = a.t;
     t.dir = 0; t.post = 0;
-    big_trsv_body<T>(b, t, qp, lds);
+    big_trsv_body<T, (NS > 8)>(b, t, qp, lds);
     b.sync();
     t.dir = 1; t.post = a.negate; t.xin = a.t.x; t.sxin = a.t.sx;
-    big_trsv_body<T>(b, t, qp, lds);
+    big_trsv_body<T, (NS > 8)>(b, t, qp, lds);
     if (a.post_phase >= 0) {
         b.sync();                                    // the solution is in global memory for wave 0
         if (b.uniform(b.wave()) == 0) {

@@ -289,11 +289,11 @@ template <class T, bool kFuse> __global__ __launch_bounds__(256, (kFuse ? 2 : 4)
     big_gemm_where(a, ntiles, swz, qp, tile);
     big_gemm2_body<T, kFuse>(b, a, qp, tile, reinterpret_cast<T*>(qpx_smem));
 }
-template <class T> __global__ __launch_bounds__(64 * kTrsvNW) void k_big_trsv(BigTrsvArgs<T> a)
+template <class T, bool kLong = false> __global__ __launch_bounds__(64 * kTrsvNW) void k_big_trsv(BigTrsvArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char qpx_smem[];
     const Block b{(int)threadIdx.x, (int)blockDim.x};
-    big_trsv_body<T>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
+    big_trsv_body<T, kLong>(b, a, (int)blockIdx.x, reinterpret_cast<T*>(qpx_smem));
 }
 QPX_BIG_KERNEL(k_big_gemv, BigGemvArgs, (big_gemv_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
 QPX_BIG_KERNEL(k_big_symv, BigSymvArgs, (big_symv_body<T>(b, a, (int)blockIdx.x, (int)blockIdx.y, reinterpret_cast<T*>(qpx_smem))), 256)
@@ -346,13 +346,14 @@ template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void* s)
 template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void* s)
 {
     static BigLdsFlags f;
-    return big_launch(k_big_trsv<T>, a, a.B, 1, 64 * kTrsvNW, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f);
+    if (a.nb > 8) { static BigLdsFlags f2; return big_launch(k_big_trsv<T, true>, a, a.B, 1, 64 * kTrsvNW, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f2); }
+    return big_launch(k_big_trsv<T, false>, a, a.B, 1, 64 * kTrsvNW, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), s, f);
 }
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void* s)
 {
     static BigLdsFlags f;
     const int outs = a.trans ? a.cols : a.rows;
-    return big_launch(k_big_gemv<T>, a, a.B, (outs + kBB - 1) / kBB, 256, big_gemv_lds_elems() * sizeof(T), s, f);
+    return big_launch(k_big_gemv<T>, a, a.B, (outs + kBB - 1) / kBB, 256, big_gemv_lds_elems(a.trans ? a.rows : a.cols) * sizeof(T), s, f);
 }
 template <class T> int launch_big_symv(const BigSymvArgs<T>& a, void* s)
 {
@@ -369,7 +370,8 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void* s)
     case 1: return big_launch(k_big_phase<T, 1>, a, a.B, 1, 64, 0, s, f);
     case 2: return big_launch(k_big_phase<T, 2>, a, a.B, 1, 64, 0, s, f);
     case 3: case 4: return big_launch(k_big_phase<T, 4>, a, a.B, 1, 64, 0, s, f);
-    default: return big_launch(k_big_phase<T, 8>, a, a.B, 1, 64, 0, s, f);
+    case 5: case 6: case 7: case 8: return big_launch(k_big_phase<T, 8>, a, a.B, 1, 64, 0, s, f);
+    default: return big_launch(k_big_phase<T, 16>, a, a.B, 1, 64, 0, s, f);
     }
 }
 template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* s)
@@ -381,7 +383,8 @@ template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void* s)
     case 1: return big_launch(k_big_solve<T, 1>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
     case 2: return big_launch(k_big_solve<T, 2>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
     case 3: case 4: return big_launch(k_big_solve<T, 4>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
-    default: return big_launch(k_big_solve<T, 8>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
+    case 5: case 6: case 7: case 8: return big_launch(k_big_solve<T, 8>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
+    default: return big_launch(k_big_solve<T, 16>, a, a.t.B, 1, 64 * kTrsvNW, lds, s, f);
     }
 }
 template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* s)
@@ -393,7 +396,8 @@ template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void* s)
     case 1: return big_launch(k_big_diag<T, 1>, a, a.p.B, 1, 256, lds, s, f);
     case 2: return big_launch(k_big_diag<T, 2>, a, a.p.B, 1, 256, lds, s, f);
     case 3: case 4: return big_launch(k_big_diag<T, 4>, a, a.p.B, 1, 256, lds, s, f);
-    default: return big_launch(k_big_diag<T, 8>, a, a.p.B, 1, 256, lds, s, f);
+    case 5: case 6: case 7: case 8: return big_launch(k_big_diag<T, 8>, a, a.p.B, 1, 256, lds, s, f);
+    default: return big_launch(k_big_diag<T, 16>, a, a.p.B, 1, 256, lds, s, f);
     }
 }
 template <class T> int launch_big_polish(const BigPolishArgs<T>& a, void* s)

@@ -355,13 +355,16 @@ template <class T> int launch_big_gemm(const BigGemmArgs<T>& a, void*)
 }
 template <class T> int launch_big_trsv(const BigTrsvArgs<T>& a, void*)
 {
-    big_grid(a.B, 1, 64 * kTrsvNW, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) { big_trsv_body<T>(b, a, qp, reinterpret_cast<T*>(l)); });
+    big_grid(a.B, 1, 64 * kTrsvNW, big_trsv_lds_elems(a.nb * kBB) * sizeof(T), [&](const Block& b, int qp, int, unsigned char* l) {
+        if (a.nb > 8) big_trsv_body<T, true>(b, a, qp, reinterpret_cast<T*>(l));
+        else big_trsv_body<T, false>(b, a, qp, reinterpret_cast<T*>(l));
+    });
     return QPX_OK;
 }
 template <class T> int launch_big_gemv(const BigGemvArgs<T>& a, void*)
 {
     const int outs = a.trans ? a.cols : a.rows;
-    big_grid(a.B, (outs + kBB - 1) / kBB, 256, big_gemv_lds_elems() * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemv_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
+    big_grid(a.B, (outs + kBB - 1) / kBB, 256, big_gemv_lds_elems(a.trans ? a.rows : a.cols) * sizeof(T), [&](const Block& b, int qp, int y, unsigned char* l) { big_gemv_body<T>(b, a, qp, y, reinterpret_cast<T*>(l)); });
     return QPX_OK;
 }
 template <class T> int launch_big_symv(const BigSymvArgs<T>& a, void*)
@@ -386,7 +389,8 @@ template <class T> int launch_big_phase(const BigPhaseArgs<T>& a, void*)
         if (ns == 1) big_phase_body<T, 1>(b, a, qp);
         else if (ns == 2) big_phase_body<T, 2>(b, a, qp);
         else if (ns <= 4) big_phase_body<T, 4>(b, a, qp);
-        else big_phase_body<T, 8>(b, a, qp);
+        else if (ns <= 8) big_phase_body<T, 8>(b, a, qp);
+        else big_phase_body<T, 16>(b, a, qp);
     });
     return QPX_OK;
 }
@@ -399,7 +403,8 @@ template <class T> int launch_big_solve(const BigSolveArgs<T>& a, void*)
         if (ns == 1) big_solve_body<T, 1>(b, a, qp, lds);
         else if (ns == 2) big_solve_body<T, 2>(b, a, qp, lds);
         else if (ns <= 4) big_solve_body<T, 4>(b, a, qp, lds);
-        else big_solve_body<T, 8>(b, a, qp, lds);
+        else if (ns <= 8) big_solve_body<T, 8>(b, a, qp, lds);
+        else big_solve_body<T, 16>(b, a, qp, lds);
     });
     return QPX_OK;
 }
@@ -419,7 +424,8 @@ template <class T> int launch_big_diag(const BigDiagArgs<T>& a, void*)
         if (ns == 1) big_diag_body<T, 1>(b, a, qp, lds);
         else if (ns == 2) big_diag_body<T, 2>(b, a, qp, lds);
         else if (ns <= 4) big_diag_body<T, 4>(b, a, qp, lds);
-        else big_diag_body<T, 8>(b, a, qp, lds);
+        else if (ns <= 8) big_diag_body<T, 8>(b, a, qp, lds);
+        else big_diag_body<T, 16>(b, a, qp, lds);
     });
     return QPX_OK;
 }

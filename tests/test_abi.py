@@ -40,7 +40,7 @@ def test_hip_library_loads_and_answers_metadata(built):
     from qpth_amd import _lib
     lib = _lib.QpxLib(built)
     assert lib.dll.qpx_abi_version() == 8
-    assert lib.dll.qpx_max_dim() == 512
+    assert lib.dll.qpx_max_dim() == 1024
     # factor blob per QP: -K, (G K)^T and ONE register image of R -- 217 KB at C2 in f64 (<= 250 KB),
     # 5.5 GB for all 65 536 QPs of C5 (<= 6 GB)
     assert 100 * 100 * 2 < lib.factor_elems(_lib.QPX_F64, 100, 100, 0) * 8 <= 250 * 1024

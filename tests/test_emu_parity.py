@@ -1045,7 +1045,9 @@ def test_f32_wide_abi_surface():
         assert dll.qpx_supported(_lib.QPX_F32_WIDE, 500, 500, 0) == 0           # the large-QP family widens on load too (round 4)
         assert dll.qpx_supported(_lib.QPX_F64, 500, 500, 0) == 0
         assert dll.qpx_factor_elems(_lib.QPX_F32_WIDE, 100, 100, 0) == dll.qpx_factor_elems(_lib.QPX_F64, 100, 100, 0)
-        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 600, 100, 0) == -2           # beyond 512 per dimension: nobody serves it
+        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 600, 100, 0) == 0            # (round 6: up to 1 024 per dimension)
+        assert dll.qpx_supported(_lib.QPX_F32_WIDE, 1100, 100, 0) == -2          # beyond 1 024 per dimension: nobody serves it
+        assert dll.qpx_polish_supported(_lib.QPX_F64, 600, 100, 0) == 0 and dll.qpx_polish_supported(_lib.QPX_F64, 500, 500, 0) == 1
         # refinement reads Q, G, A in the kernels' own type: refused, loudly
         g = load_golden("c3s_b4_n20_m10_q4_f64")
         tq = tens([np.asarray(g[k], np.float32) for k in ("Q", "p", "G", "h", "A", "b")], torch.float32, grad=False)
@@ -1116,3 +1118,25 @@ def test_mismatched_parameters_are_refused_before_any_kernel_runs():
         assert torch.allclose(z0, z1, rtol=1e-9, atol=1e-12)
         z2 = QPFunction(verbose=-1)(Q[0], p[0], G[0], h[0], A[0], b[0])
         assert z2.shape == (1, 6) and torch.allclose(z2[0], z0[0], rtol=1e-9, atol=1e-12)
+
+
+def test_sizes_beyond_512_on_the_emulator():
+    """Round 6: max(nz, nineq, neq) up to 1 024 (qpx_max_dim; the reference has no cap, batch.py:375-470).  One QP of
+    nz = 580, nineq = 600, neq = 20 -- ten blocks of 64: sixteen vector slots per lane (big_phase_body<T, 16>), the
+    substitution's rounds of streamed blocks (big_trsv_body<T, true>), sixteen blocks of the vector in the mat-vec's LDS,
+    equality constraints by projection -- through the Python surface on the kernel bodies: zhat and all six gradients
+    against the oracle (the GPU test of the same name runs 768 / 1 000 / 1 024 at batch size)."""
+    from oracle import qp_oracle as orc
+    from qpth_amd import _lib
+    B, n, m, q = 1, 580, 600, 20
+    arrs = problems.prof_qp(B, n, m, q, seed=3)
+    dl = np.ones((B, n))
+    x, y, lam, s, grads, info = orc.qp_forward_backward(*arrs, dl_dz=dl, per_qp=True)
+    with emulated(64):
+        dll = _lib.backend_for(torch.zeros(1)).dll
+        assert dll.qpx_max_dim() == 1024 and dll.qpx_supported(_lib.QPX_F64, n, m, q) == 0
+        assert dll.qpx_supported(_lib.QPX_F64, 1025, 8, 0) == -2 and dll.qpx_polish_supported(_lib.QPX_F64, n, m, q) == 0
+    z, mine = run_qpf(arrs, dl)
+    assert rel_err(z, x).max() < 1e-9
+    for k, a_, r_ in zip(("dQ", "dp", "dG", "dh", "dA", "db"), mine, grads):
+        assert np.abs(a_ - r_).max() <= 1e-8 * max(1.0, np.abs(r_).max()), k

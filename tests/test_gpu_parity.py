@@ -416,6 +416,42 @@ def test_large_qps_with_equality_constraints(dev, B, n, m, q, seed):
         assert np.abs(a_ - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max()), k
 
 
+@pytest.mark.parametrize("B,n,m,q,seed", [(4, 768, 768, 0, 21), (3, 600, 520, 40, 22), (2, 1000, 1024, 0, 23)])
+def test_sizes_beyond_512_against_the_oracle(dev, B, n, m, q, seed):
+    """Round 6: max(nz, nineq, neq) up to 1 024 (the reference has no cap, batch.py:375-470; until round 6 the library
+    refused sizes beyond 512).  The large-QP family with sixteen vector slots per lane, substitution steps streamed in rounds
+    of five blocks, sixteen blocks of the vector in the mat-vec's LDS: zhat, nu, lam, slacks and every gradient against the
+    oracle (batch-of-one semantics), float64; and as float32 tensors in float64 arithmetic within 1e-5 of the oracle on the
+    rounded data.  The finishing stage stops at 512 (its 23 vectors per QP in LDS) and says so."""
+    from oracle import qp_oracle as orc
+    from qpth_amd import _lib
+    from qpth_amd.kkt import KKTFactors
+    dll = _lib.hip().dll
+    assert dll.qpx_max_dim() == 1024 and dll.qpx_kernel_family(_lib.QPX_F64, n, m, q) == _lib.FAMILY_BIG
+    assert dll.qpx_supported(_lib.QPX_F64, 1025, 10, 0) == -2 and dll.qpx_polish_supported(_lib.QPX_F64, n, m, q) == 0
+    Q, p, G, h, A, b = problems.prof_qp(B, n, m, q, seed)
+    dl = np.random.RandomState(seed).randn(B, n)
+    x, y, lam, s, grads, info = orc.qp_forward_backward(Q, p, G, h, A, b, dl_dz=dl, per_qp=True)
+    z, mine = run_qpf([Q, p, G, h, A, b], dl, dev)
+    assert rel_err(z, x).max() < TOL
+    for k, a_, r_ in zip(("dQ", "dp", "dG", "dh", "dA", "db"), mine, grads):
+        if r_ is not None and np.size(r_):
+            assert np.abs(a_ - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max()), k
+    tQ, tp, tG, th, tA, tb = to_dev([Q, p, G, h, A, b], dev, grad=False)
+    fac = KKTFactors.build(tQ, tG, tA)
+    res = fac.ipm(tp, th, tb)
+    torch.cuda.synchronize()
+    assert int(res.status.max().item()) & 7 == 0
+    for name, a_, r_ in (("lam", res.lam, lam), ("slacks", res.slacks, s)) + ((("nu", res.nu, y),) if q else ()):
+        assert np.abs(a_.cpu().numpy() - r_).max() < 1e-5 * max(1.0, np.abs(r_).max()), name
+    arrs32 = [np.asarray(a_, np.float32) for a_ in (Q, p, G, h, A, b)]
+    x32 = orc.qp_forward_backward(*[np.asarray(a_, np.float64) for a_ in arrs32], dl_dz=dl, per_qp=True)[0]
+    z32, _ = run_qpf(arrs32, dl.astype(np.float32), dev, dtype=torch.float32)
+    e32 = rel_err(z32, x32)
+    print("n=%d m=%d q=%d float32 tensors vs the f64 oracle on the rounded data: max rel err %.2e" % (n, m, q, e32.max()))
+    assert z32.dtype == np.float32 and e32.max() <= 1e-5, e32.max()
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("shape", [(8192, 10, 100), (8192, 100, 100), (700, 64, 64), (100, 3, 3)])
 def test_batch_contraction_in_two_stages(dev, shape, dtype):
