@@ -837,9 +837,9 @@ def test_edge_cases(dev):
                                tq[2][:1, :, :3], tq[3][:1], e, e)
     # size beyond this build
     with pytest.raises(RuntimeError, match="not supported"):
-        QPFunction(verbose=-1)(torch.eye(600, dtype=torch.float64, device=dev).unsqueeze(0),
-                               torch.zeros(1, 600, dtype=torch.float64, device=dev),
-                               torch.ones(1, 1, 600, dtype=torch.float64, device=dev),
+        QPFunction(verbose=-1)(torch.eye(1100, dtype=torch.float64, device=dev).unsqueeze(0),       # (round 6: the cap is 1 024, was 512)
+                               torch.zeros(1, 1100, dtype=torch.float64, device=dev),
+                               torch.ones(1, 1, 1100, dtype=torch.float64, device=dev),
                                torch.ones(1, 1, dtype=torch.float64, device=dev), e, e)
 
 
