@@ -323,7 +323,10 @@ a non-zero diagonal.
             # float32 tensors in float64 arithmetic: the loop's answer already is the float64 solution of the data (DESIGN
             # 3.4), there is nothing for residuals in float64 to add; rounds 2-4 ran a host-composed stage here
             return res
-        raise RuntimeError("qpth_amd: no finishing stage for this size / dtype under the current knob")
+        raise RuntimeError("qpth_amd: no finishing stage (qpx_polish: KKTSolvers.IR_UNOPT, float32 refine=k) for this size / dtype "
+                           "under the current knob -- nz = %d, nineq = %d, neq = %d; it is served up to 512 per dimension "
+                           "(qpx_polish_supported).  float32 tensors run in float64 arithmetic by default (refine=None)"
+                           % (self.n, self.m, self.q))
 
     # -- QPFunctionFn.backward (qp.py:127-182) ------------------------------------------------
     def backward(self, zhat, lam, slacks, nu, dl_dz, want=(True,) * 6, shared=(False,) * 6, refine=0):

@@ -1140,3 +1140,6 @@ def test_sizes_beyond_512_on_the_emulator():
     assert rel_err(z, x).max() < 1e-9
     for k, a_, r_ in zip(("dQ", "dp", "dG", "dh", "dA", "db"), mine, grads):
         assert np.abs(a_ - r_).max() <= 1e-8 * max(1.0, np.abs(r_).max()), k
+    # the finishing stage stops at 512 per dimension and says so by name
+    with pytest.raises(RuntimeError, match="served up to 512"):
+        run_qpf([np.asarray(a_, np.float32) for a_ in arrs], dl.astype(np.float32), dtype=torch.float32, refine=2)
