@@ -540,6 +540,36 @@ def test_c5_shard_matches_oracle_and_kkt(dev):
     assert np.abs(res.lam.cpu().numpy()[sub] - lam).max() < 1e-5 * max(1.0, np.abs(lam).max())
 
 
+def test_c5_whole_batch_on_one_gpu(dev):
+    """BASELINE.json configs[4] as ONE launch sequence on one GPU: all 65 536 QPs of nz = nineq = 64 (round 5 verified one
+    GPU's share of 8 192; the round-end scaling run multiplies exactly this point).  Forward + p-gradient through the
+    one-wave kernels at eight workgroups per CU: the KKT conditions of every QP, every 128th QP (512 of them) against the
+    oracle with batch-of-one semantics, and the gradient of those against the oracle's."""
+    from oracle import qp_oracle as orc
+    from qpth_amd.kkt import KKTFactors
+    B, n, m = 65536, 64, 64
+    arrs = problems.prof_qp(B, n, m, 0, seed=8)
+    tQ, tp, tG, th, tA, tb = to_dev(arrs, dev, grad=False)
+    fac = KKTFactors.build(tQ, tG, tA)
+    res = fac.ipm(tp, th, tb)
+    ones = torch.ones(B, n, dtype=torch.float64, device=dev)
+    dp = fac.backward(res.zhat, res.lam, res.slacks, res.nu, ones, want=(False, True, False, False, False, False))[1]
+    torch.cuda.synchronize()
+    assert int(res.status.max().item()) & 7 == 0
+    stat, pinf, einf, dinf, comp, slk = kkt_residuals(tQ, tp, tG, th, tA, tb, res.zhat, res.lam, res.nu, res.slacks)
+    scale = (tp.norm(dim=1) + th.norm(dim=1)).max().item()
+    for name, v, tol in (("stationarity", stat, 1e-8), ("primal", pinf, 1e-8), ("dual sign", dinf, 1e-12),
+                         ("complementarity", comp, 1e-8), ("slack", slk, 1e-8)):
+        assert v.max().item() < tol * scale, (name, v.max().item(), scale)
+    sub = slice(0, B, 128)
+    Q, p, G, h, A, b = arrs
+    dl = np.ones((len(range(0, B, 128)), n))
+    x, y, lam, s, grads, info = orc.qp_forward_backward(Q[sub], p[sub], G[sub], h[sub], A, b, dl_dz=dl, per_qp=True, stall_policy=1)
+    assert rel_err(res.zhat.cpu().numpy()[sub], x).max() < TOL
+    assert np.abs(res.lam.cpu().numpy()[sub] - lam).max() < 1e-5 * max(1.0, np.abs(lam).max())
+    assert np.abs(dp.cpu().numpy()[sub] - grads[1]).max() < 1e-5 * max(1.0, np.abs(grads[1]).max())
+
+
 def test_c5_shape_beyond_8192_qps_runs_the_one_wave_form(dev):
     """The dispatcher switches the C5 shape (nz = nineq = 64: four tile rows) from the chain-wave form to one wave per QP
     beyond 512 QPs per launch (round 6; 8 192 until then -- qpx_api.inc: tile_waves; BASELINE.json configs[4] on ONE GPU is
