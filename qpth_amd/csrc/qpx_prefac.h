@@ -200,7 +200,7 @@ QPX_DEV void prefac_tile_body(const Block& b, const PrefactorArgs<double>& a, in
         int fcode = 0;                               // 0, or QPX_ST_Q_NOT_SPD / QPX_ST_A_RANK (= the flag of the pivot block)
         if constexpr (kEq) {
             b.template prio<3>();
-            fcode = TM::template factor_role<TM::template role_of<P>::value, false>(b, p, E, un, rd, nbr < NBN ? nbr : NBN, nn, [n, nn](int k) {
+            fcode = TM::template factor_role<TM::template role_of<P>::value, false, kEq>(b, p, E, un, rd, nbr < NBN ? nbr : NBN, nn, [n, nn](int k) {
                 const int kmax = nn - 16 * k, pos = n - 16 * k;             // pivots of the block; how many of them are Q's
                 return typename TM::PanelOf{kmax, pos >= 16 || pos >= kmax ? 1 : (pos <= 0 ? -1 : 2 + pos)};
             });

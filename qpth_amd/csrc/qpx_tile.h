@@ -430,15 +430,18 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // group carries the NEXT pivot column `vn` itself: the copy of column K+1 as it stands is started at the top of
     // pivot K, and pivot K's update is applied to the copy by one more multiply-add through the row broadcast -- the same
     // operation, on the same values, as the owner's -- so that only the reciprocal chain links one pivot to the next.
-    template <int K>
+    // kMixed: a block may hold pivots of both signs (the pre-factorisation with equality constraints), and which KIND broke down
+    // is reported: the reciprocal is then captured at its pivot (after a breakdown NaNs flow back into the diagonal entries
+    // of earlier pivots); everywhere else the sixteen reciprocals are taken once, behind the block (pivot_store).
+    template <int K, bool kMixed = false>
     static QPX_DEV void pivot16(const Block& blk, const Pos& p, T (&a)[4], T& dg, T& myr, T& vn)
     {
         constexpr int GK = K / 4, KK = K % 4;
         const T dk = blk.template row_bcast<K>(dg);
         T raw[1] = {T(0)};
         if constexpr (K < 14) raw[0] = blk.template grp_bcast<(K + 1) / 4>(a[(K + 1) % 4]);   // column K+1 before this pivot's update
-        const T r = rcp_(dk);
-        myr = p.lane == K ? r : myr;                             // (the pivots are checked together, after the block)
+        const T r = rcp_(dk);                                    // (the sixteen reciprocals are stored and checked together, after the block: pivot_store)
+        if constexpr (kMixed) myr = p.lane == K ? r : myr;
         if constexpr (K < 15) {
             const T v = p.c > K ? vn : T(0);                     // column K below the pivot, 0 above
             const T nl = -(v * r);                               // -l~
@@ -473,18 +476,25 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         st.myr = T(1);
         st.vn = blk.template grp_bcast<0>(st.a[0]);         // column 0, in every lane group
     }
-    template <int K0, int K1>
+    template <int K0, int K1, bool kMixed = false>
     static QPX_DEV void pivot_run(const Block& blk, const Pos& p, PivotState& st, int kmax)
     {
         static_for<K1 - K0>([&](auto kc) {
             constexpr int K = K0 + decltype(kc)::value;
-            if (K == 0 || kmax > K) pivot16<K>(blk, p, st.a, st.dg, st.myr, st.vn);
+            if (K == 0 || kmax > K) pivot16<K, kMixed>(blk, p, st.a, st.dg, st.myr, st.vn);
         });
     }
-    static QPX_DEV void pivot_store(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax, int sign, const PivotState& st)
+    template <bool kMixed = false>
+    static QPX_DEV void pivot_store(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax, int sign, const PivotState& st0)
     {
         T* W = scr + kW;
         T* flag = scr + kFlag;
+        // (r6) lane c's dg is final once pivot c has been taken (later pivots add nl * v with v = 0 there): the sixteen
+        // reciprocals at once, from the very values the pivots broadcast -- until round 6 every pivot selected its reciprocal
+        // into lane K (a compare and two selects per pivot on the chain); bit-identical results, C3's loop -3 %, C5's -2 %
+        // (profiles/r06y_ab_pivot_reciprocals_at_the_end.txt).  Skipped (padded) pivots keep 1.
+        PivotState st = st0;
+        if constexpr (!kMixed) st.myr = (p.lane < 16 && p.lane < kmax) ? rcp_(st0.dg) : T(1);        // (lanes 0 .. 15 hold and check them, as before)
 #pragma unroll
         for (int j = 0; j < 4; ++j) W[p.c * SS + 4 * p.g + j] = (4 * p.g + j < kmax) ? st.a[j] : T(0);
         if (p.lane < 16) rd[k0 + p.lane] = st.myr;
@@ -500,12 +510,13 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         const bool badp = blk.any(wrong && !neg), badn = blk.any(wrong && neg);
         if (p.lane == 0) flag[0] = badp ? T(1) : (badn ? T(2) : T(0));
     }
+    template <bool kMixed = false>
     static QPX_DEV void pivot_block(const Block& blk, const Pos& p, T* scr, T* rd, int k0, int kmax, int sign = 1)
     {
         PivotState st;
         pivot_load(blk, p, scr, st);
-        pivot_run<0, 16>(blk, p, st, kmax);
-        pivot_store(blk, p, scr, rd, k0, kmax, sign, st);
+        pivot_run<0, 16, kMixed>(blk, p, st, kmax);
+        pivot_store<kMixed>(blk, p, scr, rd, k0, kmax, sign, st);
     }
 
     // ---- the chain wave ahead of the tile waves across the loop's phases (kAhead; see there)
@@ -1035,17 +1046,17 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
     // panel and wave).
     // `panel(k)` = (pivots of panel k that are not identity padding, +1 / -1: their sign); npan panels.  kSweep: the
     // symmetric sweep of the first npan tile rows (update_row).  Returns 0, or the flag of the pivot block that failed.
-    template <int ROLE, bool kSweep, class PanelInfo>
+    template <int ROLE, bool kSweep, bool kMixed = false, class PanelInfo>
     static QPX_DEV int factor_role(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, int mrows, PanelInfo&& panel)
     {
-        return factor_role_impl<ROLE, kSweep, false>(blk, p0, E, scr, rd, npan, mrows, panel, [] {}, [] {}, [] {}, [] { return 0; });
+        return factor_role_impl<ROLE, kSweep, false, kMixed>(blk, p0, E, scr, rd, npan, mrows, panel, [] {}, [] {}, [] {}, [] { return 0; });
     }
     // kA (the loop kernel, kAhead): pivot block 0 is done (ahead_pivot0), X and S2 hold panel 0's old rows and E(1, 1)
     // (ahead_front) and a barrier lies behind both.  The chain wave runs `extra0` (it adds up the mat-vec's partial sums) at
     // the top of panel 0's first interval, `extra1` (the loop's residual / best-iterate / stop bookkeeping) behind pivot
     // block 1 in panel 0's second interval and `extra2` (the affine right-hand side) in panel 1's; behind panel 0's barrier X every wave asks `stopped()` and the flag of pivot block 0: -1 = the loop stops
     // (the panel of speculative work is dropped), > 0 = pivot block 0 broke down.
-    template <int ROLE, bool kSweep, bool kA, class PanelInfo, class Extra0, class Extra1, class Extra2, class Stopped>
+    template <int ROLE, bool kSweep, bool kA, bool kMixed = false, class PanelInfo, class Extra0, class Extra1, class Extra2, class Stopped>
     static QPX_DEV int factor_role_impl(const Block& blk, const Pos& p0, Regs& E, T* scr, T* rd, int npan, int mrows, PanelInfo&& panel,
                                         Extra0&& extra0, Extra1&& extra1, Extra2&& extra2, Stopped&& stopped)
     {
@@ -1063,7 +1074,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
         if constexpr (!kA) {
             if constexpr (!kChain) publish_rows<W>(p, E, scr, 0, true);
             blk.sync();
-            if constexpr (kChain) pivot_block(blk, p, scr, rd, 0, panel(0).kmax, panel(0).sign);
+            if constexpr (kChain) pivot_block<kMixed>(blk, p, scr, rd, 0, panel(0).kmax, panel(0).sign);
             blk.sync();
         }
         long long cacc[5] = {0, 0, 0, 0, 0};
@@ -1115,7 +1126,7 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
                         // waves still read this panel's)
                         blk.wave_sync();
                         pivot_load(blk, p, scr, pst);
-                        pivot_run<0, kPivotHead>(blk, p, pst, panel(k + 1).kmax);
+                        pivot_run<0, kPivotHead, kMixed>(blk, p, pst, panel(k + 1).kmax);
                     }
                 } else {
                     // the tile waves share the other operand tiles, two each: entries W and W + NWM of the list of the
@@ -1145,8 +1156,8 @@ template <int NBL, int NW, bool CH = false> struct TileMat {
             // ---- interval 2: the chain wave eliminates pivot block k+1, the tile waves stream panel k's updates
             if constexpr (kChain) {
                 if (la) {
-                    pivot_run<kPivotHead, 16>(blk, p, pst, panel(k + 1).kmax);
-                    pivot_store(blk, p, scr, rd, 16 * (k + 1), panel(k + 1).kmax, panel(k + 1).sign, pst);
+                    pivot_run<kPivotHead, 16, kMixed>(blk, p, pst, panel(k + 1).kmax);
+                    pivot_store<kMixed>(blk, p, scr, rd, 16 * (k + 1), panel(k + 1).kmax, panel(k + 1).sign, pst);
                 }
                 if constexpr (kA) {
                     if (k == 0) extra1();
